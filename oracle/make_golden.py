@@ -1,0 +1,106 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.npz by running the REAL reference
+(/root/reference) in this container.  Re-run with:  python -m oracle.make_golden
+
+Cases
+  modelnet_demo   : data/modelnet_demo_data/modelnet_test_2_{0,1}.ply, conf/modelnet.yaml
+  3dmatch_crop    : 1.2 m radius crops of the red-kitchen pair (cloud_bin_0/5), conf/3dmatch.yaml
+  3dmatch_kitchen : the full red-kitchen pair (18 977 + 19 084 pts), conf/3dmatch.yaml
+Each file holds the float32 inputs, the reference module's outputs (reference row order) with
+weights = oracle.seeded_weights.seeded_state_dict(cfg, seed=0), and the reference C++'s
+per-level points / stack lengths.  `native_*` files hold raw outputs of the reference C++ ops.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import native, ref_loader, seeded_weights   # noqa: E402
+from regtr_amd.kernel_points import K015_CENTER         # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+DATA = os.path.join(ref_loader.REF_ROOT, 'data')
+
+
+def read_ply_xyz(path):
+    raw = open(path, 'rb').read()
+    head, body = raw.split(b'end_header\n', 1)
+    n = int([l for l in head.split(b'\n') if l.startswith(b'element vertex')][0].split()[-1])
+    props = [l.split() for l in head.split(b'\n') if l.startswith(b'property')]
+    dt = np.dtype([(p[2].decode(), '<f8' if p[1] in (b'double', b'float64') else '<f4') for p in props])
+    a = np.frombuffer(body, dtype=dt, count=n)
+    return np.stack([a['x'], a['y'], a['z']], 1).astype(np.float32)
+
+
+def load_pth(path):
+    return np.asarray(torch.load(path, weights_only=False))[:, :3].astype(np.float32)
+
+
+def run_case(name, cfg_name, src, tgt, with_feats=False):
+    cfg = ref_loader.load_cfg(cfg_name)
+    model = ref_loader.build_model(cfg, 0)
+    sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
+    ref_sd = model.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), 'state_dict names differ from the reference'
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == tuple(sd[k].shape), k
+    model.load_state_dict(sd, strict=True)
+    batch = {'src_xyz': [torch.from_numpy(src)], 'tgt_xyz': [torch.from_numpy(tgt)]}
+    with torch.no_grad():
+        out = model(batch)
+    meta = batch['kpconv_meta']
+    g = {'src': src, 'tgt': tgt, 'pose': out['pose'].numpy()}
+    for k in ('src_kp', 'tgt_kp', 'src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap'):
+        g[k] = out[k][0].numpy()
+    if with_feats:
+        g['src_feat_un'] = out['src_feat_un'][0].numpy()
+        g['tgt_feat_un'] = out['tgt_feat_un'][0].numpy()
+        g['src_feat_last'] = out['src_feat'][0][-1].numpy()
+        g['tgt_feat_last'] = out['tgt_feat'][0][-1].numpy()
+    for l, (p, s) in enumerate(zip(meta['points'], meta['stack_lengths'])):
+        if l > 0:
+            g[f'points_{l}'] = p.numpy()
+        g[f'lens_{l}'] = s.numpy().astype(np.int32)
+    # neighbour tables of the coarsest level only (small); earlier ones are checked live vs oracle/_ref
+    g['neighbors_last'] = meta['neighbors'][-1].numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, f'{name}.npz'), **g)
+    print(name, {k: v.shape for k, v in g.items() if k.startswith('lens') or k == 'pose'},
+          [int(s.sum()) for s in meta['stack_lengths']])
+    print('  pose[-1]:\n', g['pose'][-1, 0])
+
+
+def native_case(name, pts, lens, dl, radius):
+    rp, rl = native.ref_subsample_batch(pts, lens, dl)
+    nb = native.ref_batch_query(pts, pts, lens, lens, radius)
+    pool = native.ref_batch_query(rp, pts, rl, lens, radius)
+    np.savez_compressed(os.path.join(GOLD, f'native_{name}.npz'), pts=pts, lens=lens, dl=np.float32(dl),
+                        radius=np.float32(radius), sub_pts=rp, sub_lens=rl, neighbors=nb, pools=pool)
+    print('native', name, rp.shape, rl, nb.shape, pool.shape)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    native.build()
+    m0 = read_ply_xyz(os.path.join(DATA, 'modelnet_demo_data', 'modelnet_test_2_0.ply'))
+    m1 = read_ply_xyz(os.path.join(DATA, 'modelnet_demo_data', 'modelnet_test_2_1.ply'))
+    k0 = load_pth(os.path.join(DATA, 'indoor/test/7-scenes-redkitchen/cloud_bin_0.pth'))
+    k5 = load_pth(os.path.join(DATA, 'indoor/test/7-scenes-redkitchen/cloud_bin_5.pth'))
+
+    def crop(p, r):
+        c = np.median(p, 0)
+        return p[np.linalg.norm(p - c, axis=1) < r]
+    c0, c5 = crop(k0, 0.9), crop(k5, 0.9)
+
+    native_case('modelnet', np.concatenate([m0, m1]), np.array([len(m0), len(m1)], np.int32), 0.06, 0.0825)
+    n0, n5 = crop(k0, 0.5), crop(k5, 0.5)
+    native_case('3dmatch_crop', np.concatenate([n0, n5]), np.array([len(n0), len(n5)], np.int32), 0.05, 0.0625)
+    run_case('modelnet_demo', 'modelnet', m0, m1)
+    run_case('3dmatch_crop', '3dmatch', c0, c5, with_feats=True)
+    run_case('3dmatch_kitchen', '3dmatch', k0, k5)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,141 @@
+// TEST INFRASTRUCTURE ONLY -- a CPU restatement of the reference's two native preprocessing ops.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+// product path (regtr_amd/) never does.
+//
+// Pinned against the unmodified reference C++ (oracle/_ref/libref_oracle.so, built by
+// oracle/Makefile from /root/reference) in tests/test_oracle.py and against the committed
+// fixtures in tests/golden/.  Citations are relative to
+// /root/reference/src/models/backbone_kpconv/cpp_wrappers/.
+//
+// Arithmetic notes that matter for bit-level parity (all float32, compiled -ffp-contract=off):
+//   * grid origin   : floor(minCorner * (1/dl)) * dl          grid_subsampling.cpp:25, cloud.h:120-143
+//   * voxel index   : (size_t)floor((p - origin) / dl)        grid_subsampling.cpp:53-55
+//   * linear key    : iX + NX*iY + NX*NY*iZ (size_t, wraps)   grid_subsampling.cpp:56
+//   * barycentre    : float sum in input order, then * (float)(1.0/count)
+//                                                             grid_subsampling.h:74-79, .cpp:87
+//   * radius test   : d2 = ((dx*dx)+dy*dy)+dz*dz ; keep iff d2 < radius*radius
+//                     cpp_utils/nanoflann/nanoflann.hpp:432-440,249-251 ; neighbors.cpp:226
+//
+// What is NOT restated: the reference's row orders, which are artefacts of libstdc++'s
+// unordered_map iteration (grid) and of std::sort on KD-tree visiting order (ties in radius).
+// The canonical orders used by the product and by this oracle are
+//   grid   : voxels in order of first appearance in the input scan, per cloud;
+//   radius : ascending (d2, support index), truncated to K, padded with Ns_total
+//            (pad value: neighbors.cpp:323-324).
+// tests compare the reference to these through a permutation / tie-aware matcher.
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace {
+
+struct Acc { int count; float x, y, z; int slot; };
+
+}  // namespace
+
+extern "C" {
+
+// points [n*3], lens [nb] -> out_pts [<= n*3] in canonical order, out_lens [nb].
+// out_keys (optional, may be NULL) receives the reference's size_t voxel key of each output row.
+// Returns the number of output rows.
+// order = 0: canonical (first appearance).  order = 1: the reference's exact row order, obtained the way
+// the reference obtains it -- iterating a libstdc++ std::unordered_map<size_t, .> filled by emplace in
+// input order (grid_subsampling.cpp:48,58-59,85); only meaningful with the same libstdc++.
+int oracle_grid_subsample(const float* points, int n, const int* lens, int nb, float dl, int order,
+                          float* out_pts, int* out_lens, uint64_t* out_keys)
+{
+    int base = 0, m = 0;
+    for (int b = 0; b < nb; b++) {
+        const int nbp = lens[b];
+        const float* P = points + 3 * (size_t)base;
+        if (nbp == 0) { out_lens[b] = 0; continue; }
+        // min_point / max_point  (cloud.cpp:27-66)
+        float mn[3] = {P[0], P[1], P[2]}, mx[3] = {P[0], P[1], P[2]};
+        for (int i = 0; i < nbp; i++)
+            for (int a = 0; a < 3; a++) {
+                float v = P[3 * i + a];
+                if (v < mn[a]) mn[a] = v;
+                if (v > mx[a]) mx[a] = v;
+            }
+        const float inv = 1 / dl;                              // grid_subsampling.cpp:25 "(1/sampleDl)"
+        float org[3];
+        for (int a = 0; a < 3; a++) org[a] = std::floor(mn[a] * inv) * dl;
+        const size_t NX = (size_t)std::floor((mx[0] - org[0]) / dl) + 1;   // :30
+        const size_t NY = (size_t)std::floor((mx[1] - org[1]) / dl) + 1;   // :31
+        std::unordered_map<size_t, int> slot;                  // key -> index into acc (first-appearance order)
+        std::vector<Acc> acc;
+        std::vector<uint64_t> keys;
+        for (int i = 0; i < nbp; i++) {
+            const float x = P[3 * i], y = P[3 * i + 1], z = P[3 * i + 2];
+            const size_t iX = (size_t)std::floor((x - org[0]) / dl);       // :53-55
+            const size_t iY = (size_t)std::floor((y - org[1]) / dl);
+            const size_t iZ = (size_t)std::floor((z - org[2]) / dl);
+            const uint64_t key = iX + NX * iY + NX * NY * iZ;              // :56
+            auto it = slot.find(key);
+            int s;
+            if (it == slot.end()) {
+                s = (int)acc.size();
+                slot.emplace(key, s);
+                acc.push_back(Acc{0, 0.f, 0.f, 0.f, s});
+                keys.push_back(key);
+            } else s = it->second;
+            acc[s].count += 1;                                 // grid_subsampling.h:74-79
+            acc[s].x += x; acc[s].y += y; acc[s].z += z;
+        }
+        std::vector<int> emit;
+        if (order == 1) for (auto& kv : slot) emit.push_back(kv.second);
+        else for (size_t s = 0; s < acc.size(); s++) emit.push_back((int)s);
+        for (int s : emit) {
+            const float w = (float)(1.0 / acc[s].count);       // .cpp:87 + cloud.h:120 (double -> float)
+            out_pts[3 * (size_t)m + 0] = acc[s].x * w;
+            out_pts[3 * (size_t)m + 1] = acc[s].y * w;
+            out_pts[3 * (size_t)m + 2] = acc[s].z * w;
+            if (out_keys) out_keys[m] = keys[s];
+            m++;
+        }
+        out_lens[b] = (int)acc.size();
+        base += nbp;
+    }
+    return m;
+}
+
+// Brute-force fixed-radius neighbours restricted to the same cloud.
+// out_idx [nq*K] canonical order, padded with ns ; out_cnt [nq] = UNTRUNCATED in-radius count
+// (the reference's row width is max over out_cnt, neighbors.cpp:290-293).
+// out_tie (optional) [nq]: 1 if the K-th and (K+1)-th smallest d2 are equal (the reference's choice
+// among them is unspecified), else 0.
+void oracle_radius_neighbors(const float* q, int nq, const float* s, int ns,
+                             const int* q_lens, const int* s_lens, int nb,
+                             float radius, int K, int* out_idx, int* out_cnt, uint8_t* out_tie)
+{
+    const float r2 = radius * radius;                          // neighbors.cpp:226
+    int qb = 0, sb = 0;
+    std::vector<std::pair<float, int>> cand;
+    for (int b = 0; b < nb; b++) {
+        for (int i = qb; i < qb + q_lens[b]; i++) {
+            cand.clear();
+            const float qx = q[3 * (size_t)i], qy = q[3 * (size_t)i + 1], qz = q[3 * (size_t)i + 2];
+            for (int j = sb; j < sb + s_lens[b]; j++) {
+                const float dx = qx - s[3 * (size_t)j], dy = qy - s[3 * (size_t)j + 1],
+                            dz = qz - s[3 * (size_t)j + 2];
+                float d2 = 0.f;                                // nanoflann.hpp:432-440 (L2_Simple_Adaptor)
+                d2 = d2 + dx * dx; d2 = d2 + dy * dy; d2 = d2 + dz * dz;
+                if (d2 < r2) cand.emplace_back(d2, j);         // nanoflann.hpp:249-251 strict <
+            }
+            std::sort(cand.begin(), cand.end());               // (d2, index) ascending = canonical
+            const int c = (int)cand.size();
+            out_cnt[i] = c;
+            for (int k = 0; k < K; k++) out_idx[(size_t)i * K + k] = k < c ? cand[k].second : ns;
+            if (out_tie) out_tie[i] = (c > K && cand[K - 1].first == cand[K].first) ? 1 : 0;
+        }
+        qb += q_lens[b];
+        sb += s_lens[b];
+    }
+}
+
+}  // extern "C"
