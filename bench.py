@@ -1,0 +1,259 @@
+"""Throughput benchmark of the RegTR correspondence-inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one forward of the hot path (preprocess -> KPConv encoder -> 6 cross-attention layers -> head ->
+weighted Procrustes) over one batch of `--pairs` synthetic 3DMatch-sized pairs (BASELINE.json configs[2]: ~20k points
+per cloud, conf/3dmatch.yaml architecture, random-init weights), inputs resident in HBM.  Independent pairs shard across
+ranks with no data-path collective; the only RCCL traffic is one all_gather of the poses at the end of the timed region.
+Rank 0 prints ONE JSON line (metric pairs/s, whole-job aggregate) with `roofline` (KPConv gather, HBM bound) and
+`cpu_baseline` (the CPU oracle port timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# synthetic 3DMatch-like pairs
+# ----------------------------------------------------------------------------------------------------------------
+def synth_scene(rng, target_pts, voxel=0.025):
+    """Planes and boxes of a room corner sampled densely, then voxel-averaged at 2.5 cm like the 3DMatch fragments."""
+    area = target_pts * voxel * voxel * 1.25
+    side = np.sqrt(area / 3.2)
+    surf = []
+
+    def rect(o, u, v, n):
+        ab = rng.random((n, 2))
+        return o + ab[:, :1] * u + ab[:, 1:] * v
+
+    dens = 14.0 / (voxel * voxel)
+    X, Y, Z = 1.6 * side, 1.2 * side, 0.9 * side
+    surf.append(rect(np.zeros(3), np.array([X, 0, 0]), np.array([0, Y, 0]), int(X * Y * dens)))          # floor
+    surf.append(rect(np.zeros(3), np.array([X, 0, 0]), np.array([0, 0, Z]), int(X * Z * dens)))          # wall
+    surf.append(rect(np.zeros(3), np.array([0, Y, 0]), np.array([0, 0, Z]), int(Y * Z * dens)))          # wall
+    for _ in range(3):                                                                                   # furniture
+        o = np.array([rng.uniform(0.1, X - 0.7), rng.uniform(0.1, Y - 0.7), 0.0])
+        w, d, h = rng.uniform(0.3, 0.6, 3)
+        surf.append(rect(o + [0, 0, h], np.array([w, 0, 0]), np.array([0, d, 0]), int(w * d * dens)))
+        surf.append(rect(o, np.array([w, 0, 0]), np.array([0, 0, h]), int(w * h * dens)))
+        surf.append(rect(o, np.array([0, d, 0]), np.array([0, 0, h]), int(d * h * dens)))
+    p = np.concatenate(surf) + rng.normal(scale=0.002, size=(sum(len(s) for s in surf), 3))
+    key = np.floor(p / voxel).astype(np.int64)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    out = np.zeros((len(cnt), 3))
+    np.add.at(out, inv.ravel(), p)
+    out /= cnt[:, None]
+    return out[rng.permutation(len(out))], X
+
+
+def random_se3(rng, rot_deg=45.0, trans=0.5):
+    axis = rng.standard_normal(3); axis /= np.linalg.norm(axis)
+    ang = np.deg2rad(rng.uniform(0, rot_deg))
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+    t = rng.standard_normal(3); t = t / np.linalg.norm(t) * rng.uniform(0, trans)
+    return R, t
+
+
+def synth_pair(pair_id, pts_per_cloud=20000):
+    rng = np.random.default_rng(1000 + pair_id)
+    scene, X = synth_scene(rng, int(pts_per_cloud / 0.72))
+    src = scene[scene[:, 0] < 0.72 * X]
+    tgt = scene[scene[:, 0] > 0.28 * X]
+    R, t = random_se3(rng)
+    tgt = tgt @ R.T + t + rng.normal(scale=0.005, size=tgt.shape)        # augment_noise 0.005 (3dmatch.yaml:7)
+    src = src + rng.normal(scale=0.005, size=src.shape)
+    return src.astype(np.float32), tgt.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
+    """B_kp = Nq*H*(4 + 12 + 4*Cin) + Nq*(12 + 4*Cout) + 15*Cin*Cout*4 (fp32 feats, int32 idx)."""
+    return nq * H * (4 + 12 + 4 * cin) + nq * (12 + 4 * cout) + kp * cin * cout * 4
+
+
+def measure_kpconv_roofline(model, batch, reps=5):
+    """Times every KPConv gather launch (k_kpconv_gather) with HIP events on the stream it is enqueued on (torch's
+    current stream) during real forwards; achieved = sum of algorithmic bytes / sum of durations."""
+    from regtr_amd import ops, _lib
+    records = []
+    orig = _lib.lib().regtr_kpconv_gather
+
+    class Timed:
+        def __call__(self, *a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            st = orig(*a)
+            e1.record()
+            nq, H, cin = a[1], a[5], a[7]
+            records.append((e0, e1, nq, H, cin))
+            return st
+    L = _lib.lib()
+    # ctypes function objects cannot be replaced on the CDLL; route through the ops module instead
+    real_kpconv = ops.kpconv
+
+    def timed_kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent):
+        nq, H = nbr.shape
+        ns, Cin = x.shape
+        KP = kernel_points.shape[0]
+        flag = torch.empty(ns, dtype=torch.float32, device=x.device)
+        _lib.check(L.regtr_rowsum_positive(_lib.ptr(x), ns, Cin, _lib.ptr(flag), _lib.stream()), 'rowsum')
+        wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=x.device)
+        num = torch.empty(nq, dtype=torch.float32, device=x.device)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_xyz), nq, _lib.ptr(s_xyz), ns, _lib.ptr(nbr), H, _lib.ptr(x), Cin,
+                                         _lib.ptr(flag), _lib.ptr(kernel_points), KP, float(extent), _lib.ptr(wf),
+                                         _lib.ptr(num), _lib.stream()), 'gather')
+        e1.record()
+        out = ops.gemm(wf, w_flat, row_div=num)
+        e2.record()
+        records.append((e0, e1, e2, nq, H, Cin, w_flat.shape[1]))
+        return out
+    ops.kpconv = timed_kpconv
+    try:
+        for _ in range(reps):
+            model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
+        torch.cuda.synchronize()
+    finally:
+        ops.kpconv = real_kpconv
+    t_gather = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
+    t_gemm = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3
+    alg = sum(kpconv_algorithmic_bytes(r[3], r[4], r[5], r[6]) for r in records)
+    # the gather kernel itself moves the gathered rows + indices + xyz and writes WF
+    alg_gather = sum(r[3] * r[4] * (4 + 12 + 4 * r[5]) + r[3] * (12 + 4 * 15 * r[5] + 4) for r in records)
+    n_launch = len(records)
+    return {
+        'kernel': 'k_kpconv_gather',
+        'launches_per_step': n_launch // reps,
+        'avg_launch_us': t_gather / n_launch * 1e6,
+        'achieved_gather_kernel_GBs': alg_gather / t_gather / 1e9,
+        'achieved_kpconv_op_GBs': alg / (t_gather + t_gemm) / 1e9,
+        'alg_bytes_per_step': alg / reps,
+        'gather_s_per_step': t_gather / reps, 'gemm_s_per_step': t_gemm / reps,
+    }
+
+
+def cpu_baseline(cfg, pairs, max_seconds=30.0):
+    """The CPU oracle port (oracle/regtr_ref.py; preprocessing through the unmodified reference C++ when oracle/_ref is
+    present) on this box's host cores, same workload, bounded sample."""
+    from oracle import native, regtr_ref, seeded_weights
+    from regtr_amd.kernel_points import K015_CENTER
+    torch.set_num_threads(os.cpu_count())
+    sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
+    use_ref = native.have_ref()
+    times, stages = [], []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        for i, (s, t) in enumerate(pairs):
+            tm = []
+            t0 = time.perf_counter()
+            regtr_ref.regtr_forward(sd, cfg, [s], [t], use_ref_cpp=use_ref, timings=tm)
+            dt = time.perf_counter() - t0
+            if i > 0 or len(pairs) == 1:
+                times.append(dt); stages.append(tm[0])
+            if time.perf_counter() - t_start > max_seconds and times:
+                break
+    med = float(np.median(times))
+    st = np.median(np.array(stages), axis=0)
+    return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{len(times)} timed pair(s) after 1 warm-up, same synthetic ~{len(pairs[0][0])}-pt pairs, fp32 torch CPU '
+                      f'restatement; preprocessing by {"the unmodified reference C++ (oracle/_ref)" if use_ref else "the C++ oracle restatement"}; '
+                      f'median s/pair {med:.2f} = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs', type=int, default=4, help='pairs per step per GPU (one forward)')
+    ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from regtr_amd import RegTR, load_config
+    from regtr_amd.distributed import gather_poses
+    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
+    torch.manual_seed(0); np.random.seed(0)
+    model = RegTR(cfg).to(dev).eval()
+
+    pairs = [synth_pair(rank * 100003 + i, args.points) for i in range(args.pairs)]
+    batch = {'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in pairs],
+             'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in pairs]}
+    pair_ids = torch.arange(args.pairs, device=dev, dtype=torch.int32) + rank * args.pairs
+
+    def step():
+        return model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})['pose'][-1]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    poses = None
+    for _ in range(args.steps):
+        poses = step()
+    all_poses, all_ids = gather_poses(poses.reshape(-1, 12), pair_ids) if dist else (poses.reshape(-1, 12), pair_ids)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert all_poses.shape[0] == args.pairs * world and torch.isfinite(all_poses).all()
+
+    if rank == 0:
+        total_pairs = world * args.steps * args.pairs
+        res = {
+            'metric': 'point-cloud pairs/sec (3DMatch ~20k pts)', 'value': total_pairs / elapsed, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[2]: 3DMatch-size pairs, full KPConv encoder + 6-layer cross-attn + SVD',
+                       'pairs_per_step_per_gpu': args.pairs,
+                       'points_per_cloud': [int(np.mean([len(s) for s, _ in pairs])), int(np.mean([len(t) for _, t in pairs]))],
+                       'arch': 'conf/3dmatch.yaml, random-init weights', 'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
+        }
+        if not args.no_roofline:
+            r = measure_kpconv_roofline(model, batch)
+            res['roofline'] = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': None, 'detail': r}
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(4)])
+        print(json.dumps(res))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

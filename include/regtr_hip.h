@@ -1,0 +1,117 @@
+/*
+ * regtr_hip.h -- C ABI of libregtr_hip.so: the gfx950 (MI355X) kernels of the RegTR correspondence-inference hot
+ * path.  Plain pointers and sizes only, no torch types: any host (ctypes, cgo, JNI, a C++ pipeline) can bind it.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued, nothing synchronises;
+ *   - return value: 0 = OK, <0 = error (REGTR_ERR_*); nothing throws across the boundary.  The Python shim raises
+ *     RuntimeError on a non-zero status, as the reference's CPython wrappers do
+ *     (cpp_neighbors/wrapper.cpp:77,95,133,203);
+ *   - clouds of a batch are STACKED: rows [seg_off[c], seg_off[c+1]) belong to cloud c; seg_off is int32 [n_clouds+1]
+ *     ON THE DEVICE so that data-dependent level sizes never have to visit the host between kernels.  `*_cap`
+ *     arguments are host-known upper bounds used only to size launches and buffers.
+ *   - indices are int32; the shadow / pad index is the total number of support rows (neighbors.cpp:323-324).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/src):
+ *   regtr_grid_subsample      cpp_subsampling.subsample_batch     models/backbone_kpconv/cpp_wrappers/cpp_subsampling/wrapper.cpp:62-333
+ *                             = batch_grid_subsampling            .../grid_subsampling/grid_subsampling.cpp:109-211
+ *                             (GPU twin batch_grid_subsampling_kpconv_gpu, models/backbone_kpconv/kpconv.py:213-240)
+ *   regtr_cellgrid_build +
+ *   regtr_radius_query        cpp_neighbors.batch_query           .../cpp_neighbors/wrapper.cpp:58-238
+ *                             = batch_nanoflann_neighbors         .../cpp_neighbors/neighbors/neighbors.cpp:211-332
+ *                             (GPU twin batch_neighbors_kpconv_gpu, kpconv.py:261-288)
+ *   regtr_kpconv_gather +
+ *   regtr_gemm_f32            KPConv.forward                      models/backbone_kpconv/kpconv_blocks.py:269-414
+ *   regtr_maxpool_gather      max_pool                            kpconv_blocks.py:127-143
+ *   regtr_instnorm_*          BatchNormBlock (InstanceNorm1d) + LeakyReLU + residual   kpconv_blocks.py:497-519,556-561,741
+ *   regtr_gemm_f32            nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
+ *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
+ *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
+ *   regtr_mha_fwd             nn.MultiheadAttention core          transformers.py:197-226
+ *   regtr_weighted_procrustes pose assembly + compute_rigid_transform   regtr.py:185-203, utils/se3_torch.py:108-154
+ */
+#ifndef REGTR_HIP_H
+#define REGTR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REGTR_OK 0
+#define REGTR_ERR_LAUNCH (-1)
+#define REGTR_ERR_ARG (-2)
+#define REGTR_ERR_WORKSPACE (-3)
+
+/* ---- preprocessing ---------------------------------------------------------------------------------------- */
+
+size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds);
+
+/* Voxel-grid barycentres of every cloud.  xyz [n_cap,3] (live rows: seg_off[n_clouds]); out_xyz [n_cap,3] receives
+ * M <= n rows, clouds stacked in order, voxels of a cloud in order of first appearance in the input;
+ * out_seg_off [n_clouds+1].  Barycentres are bit-identical to the reference's (float32 sums in input order). */
+int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
+                         int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
+
+size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds);
+
+/* Builds the support-point cell grid for `radius` into ws (kept by the caller, reused by any number of queries). */
+int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds, int ns_cap, float radius, void* ws,
+                         size_t ws_bytes, void* stream);
+
+/* Fixed-radius neighbours within the same cloud.  out_idx [nq_cap,K]: ascending (d2, support index), strict d2 < r2
+ * in the reference's float32 arithmetic, padded with Ns_total = s_seg_off[n_clouds].  out_count [nq_cap] (optional):
+ * untruncated in-ball count; out_max_count (optional, device int zeroed by the caller): max over out_count, i.e. the
+ * row width the reference's batch_query would return.  1 <= K <= 448.  ns_cap / ws_bytes as given to the build. */
+int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
+                       int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
+                       int* out_count, int* out_max_count, void* stream);
+
+/* ---- KPConv encoder --------------------------------------------------------------------------------------- */
+
+/* flag[j] = (sum_c x[j,c] > 0) ? 1 : 0   -- the per-support term of the reference's normaliser (kpconv_blocks.py:409-410) */
+int regtr_rowsum_positive(const float* x, int n, int C, float* flag, void* stream);
+
+/* wf [nq, KP*Cin] (kernel point major, channel minor), num [nq] = max(1, #positive neighbours).  nbr [nq,H] int32,
+ * x [ns,Cin], flag [ns], kernel_points [KP,3], KP <= 16. */
+int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
+                        int Cin, const float* flag, const float* kernel_points, int KP, float extent, float* wf,
+                        float* num, void* stream);
+
+int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream);
+
+size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C);
+int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int max_len, int C, float eps, float* stats,
+                         void* ws, size_t ws_bytes, void* stream);
+/* y = act((x-mean)*rstd [+ residual | + (residual-rmean)*rrstd]); act: 0 none, 1 LeakyReLU(slope); y may alias x */
+int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int max_len, int C, const float* stats,
+                         const float* residual, const float* res_stats, int act, float slope, float* y, void* stream);
+
+/* ---- dense ------------------------------------------------------------------------------------------------- */
+
+/* C[M,N] = act(A[M,K] B[K,N] / row_div[m] + bias[n]) + residual[m,n] ; float32 MFMA ; act: 0 none, 1 ReLU */
+int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                   const float* bias, const float* row_div, const float* residual, int ldr, int act, void* stream);
+
+int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
+                    float* y, float* y_plain, void* stream);
+
+int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale, const float* dim_t, float* pe,
+                      void* stream);
+
+/* ---- attention + pose -------------------------------------------------------------------------------------- */
+
+int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                  const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
+                  void* stream);
+
+/* kp [n_total,3], corr [L,n_total,3], logit [L,n_total], seg_off [2*n_pairs+1] -> pose [L,n_pairs,3,4] */
+int regtr_weighted_procrustes(const float* kp, const float* corr, const float* logit, const int* seg_off, int n_pairs,
+                              int n_total, int n_layers, float* pose, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REGTR_HIP_H */

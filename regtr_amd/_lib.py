@@ -1,0 +1,76 @@
+"""ctypes binding of libregtr_hip.so (the C ABI declared in include/regtr_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails this raises, so a GPU run can never
+silently pass on some other code path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libregtr_hip.so')
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_F = _c.c_float
+_Z = _c.c_size_t
+
+# name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
+SIGNATURES = {
+    'regtr_grid_subsample_ws_bytes': (_Z, [_I, _I]),
+    'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    'regtr_cellgrid_ws_bytes': (_Z, [_I, _I]),
+    'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
+    'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
+    'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P]),
+    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
+    'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
+    'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),
+    'regtr_instnorm_apply': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P]),
+    'regtr_gemm_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
+    'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
+    'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+}
+
+_ERR = {-1: 'kernel launch failed', -2: 'invalid argument', -3: 'workspace too small'}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m regtr_amd.build` '
+                               '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f'{what}: {_ERR.get(status, "error")} (status {status})')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on a GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('regtr_amd ops need GPU tensors (no CPU fallback)')
+    if not t.is_contiguous():
+        raise RuntimeError('regtr_amd ops need contiguous tensors')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,152 @@
+// Multi-head attention core (scaled QK^T -> softmax -> AV) on the CDNA4 matrix cores, float32 in / float32
+// accumulate (v_mfma_f32_32x32x2_f32).  Implements the arithmetic of nn.MultiheadAttention between the in- and
+// out-projections for the four attention calls of a RegTR cross-encoder layer
+//   /root/reference/src/models/transformer/transformers.py:197-201,206-210 (self) and :217-226 (cross)
+// on PACKED variable-length sequences: cloud c's queries attend the keys/values of cloud kv_of[c]
+// (self: kv_of[c] = c ; cross: the partner cloud of the pair).  No padding, no key_padding_mask needed.
+//
+// One 64-lane wavefront owns a 32-query tile of one head and streams 32-key tiles, flash style:
+//   S^T = K Q^T is computed with K as the A operand and the (pre-scaled) queries as B, so each lane ends up with the
+//   scores of ONE query row (column of S^T) for 16 keys; the two half-waves hold complementary key sets, so the row
+//   max / row sum need 15 in-register ops and a single cross-half exchange -- no LDS round trip for the softmax.
+//   P^T is then fed straight back as the B operand of O^T += V^T P^T: step s of the contraction uses the key that
+//   accumulator register s of this half-wave already corresponds to, so the probabilities never leave registers.
+// K / V tiles are staged through LDS with an odd row stride (33) so both fragment read patterns are conflict free.
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 32;       // head dimension handled by this kernel
+constexpr int TQ = 32, TK = 32;
+constexpr int LDS_STRIDE = HD + 1;
+
+struct MhaArgs {
+    const float* q; const float* k; const float* v;   // row-major, leading dims ldq / ldk / ldv
+    float* out;
+    const int* seg_off; const int* kv_of;
+    int ldq, ldk, ldv, ldo, n_heads;
+    float scale;
+};
+
+// accumulator register r of half-wave `hi` holds matrix row  (r & 3) + 8 * (r >> 2) + 4 * hi
+__device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
+{
+    __shared__ float Ks[TK * LDS_STRIDE];
+    __shared__ float Vs[TK * LDS_STRIDE];
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.z, head = blockIdx.y;
+    const int q_begin = g.seg_off[cloud], q_end = g.seg_off[cloud + 1];
+    const int q0 = q_begin + blockIdx.x * TQ;
+    if (q0 >= q_end) return;
+    const int kc = g.kv_of[cloud];
+    const int k_begin = g.seg_off[kc], nk = g.seg_off[kc + 1] - k_begin;
+    const int hoff = head * HD;
+
+    // B operand of S^T = K Q^T : lane holds Q[q0 + l31][2 s + hi] * scale for s = 0..15
+    float qreg[16];
+    {
+        const int qrow = q0 + l31;
+        const bool live = qrow < q_end;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            qreg[s] = live ? g.q[(size_t)qrow * g.ldq + hoff + 2 * s + hi] * g.scale : 0.f;
+    }
+
+    floatx16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = 0; kt < nk; kt += TK) {
+        // stage the K and V tiles: 32 rows x 32 floats each; a row is one 128-B line, 8 lanes per row
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            const int krow = kt + row;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (krow < nk) {
+                kv = *(const float4*)(g.k + (size_t)(k_begin + krow) * g.ldk + hoff + c4);
+                vv = *(const float4*)(g.v + (size_t)(k_begin + krow) * g.ldv + hoff + c4);
+            }
+            float* kd = &Ks[row * LDS_STRIDE + c4];
+            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            float* vd = &Vs[row * LDS_STRIDE + c4];
+            vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+        }
+        __syncthreads();
+
+        // S^T tile: rows = keys, cols = queries
+        floatx16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * LDS_STRIDE + 2 * s + hi], qreg[s], sc, 0, 0, 0);
+
+        // online softmax for query column l31 (keys acc_row(r, hi) of this tile)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (kt + acc_row(r, hi) >= nk) sc[r] = -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, RG_WAVE));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = expf(sc[r] - m_new);
+            psum += sc[r];
+        }
+        psum += __shfl_xor(psum, 32, RG_WAVE);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= alpha;
+
+        // O^T += V^T P^T : contraction step s uses key acc_row(s, hi) on both operands
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[acc_row(s, hi) * LDS_STRIDE + l31], sc[s], o, 0, 0, 0);
+    }
+
+    const int qrow = q0 + l31;
+    if (qrow < q_end) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // empty key set -> zeros
+        float* dst = g.out + (size_t)qrow * g.ldo + hoff;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const int d = 8 * r4 + 4 * hi;   // acc_row(4 * r4 + j, hi) = j + 8 * r4 + 4 * hi
+            *(float4*)(dst + d) = make_float4(o[4 * r4] * inv, o[4 * r4 + 1] * inv, o[4 * r4 + 2] * inv, o[4 * r4 + 3] * inv);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// q, k, v: [N_total, *] row-major views (leading dims ldq/ldk/ldv) holding n_heads * 32 columns each;
+// out [N_total, ldo].  seg_off [n_clouds + 1] and kv_of [n_clouds] live on the device.
+// max_len = longest query segment (host-known bound used for the launch grid).
+int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
+                  const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
+                  void* stream)
+{
+    if (!q || !k || !v || !out || !seg_off || !kv_of || n_clouds < 1 || n_heads < 1 || max_len < 0) return RG_ERR_ARG;
+    if (head_dim != HD) return RG_ERR_ARG;
+    if ((ldk | ldv | ldo) % 4 || (((uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
+    if (max_len == 0) return RG_OK;
+    MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
+    k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, (hipStream_t)stream>>>(g);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,200 @@
+// KPConv irregular neighbour gather + kernel-point correlation for gfx950, and the strided-block max-pool gather.
+// Reference: KPConv.forward (non-deformable, 'linear' influence, 'sum' aggregation)
+//   /root/reference/src/models/backbone_kpconv/kpconv_blocks.py:269-414, max_pool :127-143.
+//
+// The reference materialises (Nq,H,15,3) differences, (Nq,H,15) influences and (Nq,H,Cin) gathered features as
+// separate tensors.  Here one pass per query tile does everything on chip:
+//   phase 1  lanes = neighbours: coalesced read of the index row, gather of the neighbour xyz, centred offsets and
+//            the "feature sum > 0" flags into LDS;
+//   phase 2  lanes = (neighbour, kernel point): 15 linear influences max(0, 1 - |y - kp_k| / extent) into an
+//            LDS-staged [H][16] tile (each lane keeps its kernel point in registers);
+//   phase 3  lanes = channels: the neighbour feature rows are gathered once (row-contiguous, line-sized reads),
+//            influences are broadcast from LDS as 128-bit reads and 15 accumulators per channel stay in registers.
+// Output is the weighted-feature matrix WF[q][k*Cin + c] that feeds the MFMA contraction with the [15*Cin, Cout]
+// kernel weights (gemm.hip), plus the reference's data-dependent normaliser
+//   num[q] = max(1, #{h : sum_c x[n_qh, c] > 0})            kpconv_blocks.py:409-411
+// which the GEMM epilogue divides by.
+#include "common.h"
+
+namespace {
+
+constexpr int KP_PAD = 16;   // kernel points padded to 16 per neighbour (15 used)
+constexpr int GATHER_WAVES = 4;
+
+// flag[j] = (sum_c x[j, c] > 0) for every support row; the shadow row (index ns) is 0 by construction.
+__global__ void __launch_bounds__(256) k_rowsum_positive(const float* __restrict__ x, int n, int C, float* __restrict__ flag)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = rg_lane();
+    float s = 0.f;
+    for (int c = lane; c < C; c += RG_WAVE) s += x[(size_t)row * C + c];
+    s = rg_wave_sum(s);
+    if (lane == 0) flag[row] = s > 0.f ? 1.f : 0.f;
+}
+
+struct GatherArgs {
+    const float* q_xyz; const float* s_xyz; const int* nbr; const float* x; const float* flag; const float* kp;
+    float* wf; float* num;
+    int nq, ns, H, Cin, KP;
+    float extent;
+};
+
+// LQ = lanes per query (16, 32 or 64); a wave handles 64 / LQ queries at a time.
+template <int LQ>
+__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(GatherArgs g)
+{
+    constexpr int QW = RG_WAVE / LQ;
+    extern __shared__ __align__(16) float smem[];
+    const int wave = threadIdx.x >> 6, lane = rg_lane();
+    const int H = g.H;
+    // per-wave LDS: w[QW][H][16] | rel[QW][H][3] | nidx[QW][H] | flag[QW][H]
+    const int per_wave = (QW * H * (KP_PAD + 5) + 3) & ~3;   // keep every wave's tile 16-B aligned
+    float* w_s = smem + (size_t)wave * per_wave;
+    float* rel_s = w_s + QW * H * KP_PAD;
+    int* idx_s = (int*)(rel_s + QW * H * 3);
+    float* flg_s = (float*)(idx_s + QW * H);
+
+    const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
+    if (q0 >= g.nq) return;   // wave-uniform
+
+    // ---- phase 1: neighbour indices, centred offsets, positivity flags
+    for (int e = lane; e < QW * H; e += RG_WAVE) {
+        const int qi = e / H, h = e - qi * H, q = q0 + qi;
+        int idx = g.ns;
+        float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f;
+        if (q < g.nq) {
+            idx = g.nbr[(size_t)q * H + h];
+            float sx = 1e6f, sy = 1e6f, sz = 1e6f;            // shadow support point  (kpconv_blocks.py:309)
+            if (idx < g.ns) {
+                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
+                f = g.flag[idx];
+            }
+            rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
+        }
+        idx_s[e] = idx; flg_s[e] = f;
+        rel_s[3 * e] = rx; rel_s[3 * e + 1] = ry; rel_s[3 * e + 2] = rz;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 2: linear influences; lane's kernel point is fixed (k = lane % 16)
+    {
+        const int k = lane & (KP_PAD - 1);
+        const bool kvalid = k < g.KP;
+        const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+        for (int e = lane; e < QW * H * KP_PAD; e += RG_WAVE) {
+            const int qh = e >> 4;   // (qi*H + h)
+            const float dx = rel_s[3 * qh] - kx, dy = rel_s[3 * qh + 1] - ky, dz = rel_s[3 * qh + 2] - kz;
+            float d2;
+            {
+#pragma clang fp contract(off)
+                d2 = (dx * dx + dy * dy) + dz * dz;                               // kpconv_blocks.py:326-329
+            }
+            float wv = 1.f - sqrtf(d2) / g.extent;                                // :368
+            w_s[e] = (kvalid && wv > 0.f) ? wv : 0.f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- phase 3: lanes = channels of one query
+    const int qi = lane / LQ, cl = lane % LQ, q = q0 + qi;
+    if (q >= g.nq) return;
+    const float* wq = w_s + (size_t)qi * H * KP_PAD;
+    const int* iq = idx_s + qi * H;
+    const int Cin = g.Cin;
+    for (int c = cl; c < Cin; c += LQ) {
+        float acc[KP_PAD];
+#pragma unroll
+        for (int k = 0; k < KP_PAD; k++) acc[k] = 0.f;
+        for (int h = 0; h < H; h++) {
+            const int idx = iq[h];
+            const float xv = idx < g.ns ? g.x[(size_t)idx * Cin + c] : 0.f;       // zero shadow feature (:388)
+            const float4* w4 = (const float4*)(wq + h * KP_PAD);
+#pragma unroll
+            for (int j = 0; j < KP_PAD / 4; j++) {
+                const float4 wv = w4[j];
+                acc[4 * j + 0] = fmaf(wv.x, xv, acc[4 * j + 0]);
+                acc[4 * j + 1] = fmaf(wv.y, xv, acc[4 * j + 1]);
+                acc[4 * j + 2] = fmaf(wv.z, xv, acc[4 * j + 2]);
+                acc[4 * j + 3] = fmaf(wv.w, xv, acc[4 * j + 3]);
+            }
+        }
+        float* o = g.wf + (size_t)q * g.KP * Cin + c;
+#pragma unroll
+        for (int k = 0; k < KP_PAD; k++)
+            if (k < g.KP) o[(size_t)k * Cin] = acc[k];
+    }
+    if (cl == 0) {
+        float cnt = 0.f;
+        const float* fq = flg_s + qi * H;
+        for (int h = 0; h < H; h++) cnt += fq[h];
+        g.num[q] = fmaxf(cnt, 1.f);                                               // :410-411
+    }
+}
+
+// out[q, c] = max_h x_pad[nbr[q, h], c]   with a zero shadow row   (kpconv_blocks.py:127-143)
+__global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
+                                                        int nq, int H, float* __restrict__ out)
+{
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int lane = rg_lane();
+    const int* row = nbr + (size_t)q * H;
+    for (int c = lane * 4; c < C; c += RG_WAVE * 4) {
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int h = 0; h < H; h++) {
+            const int idx = row[h];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < ns) v = *(const float4*)(x + (size_t)idx * C + c);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        *(float4*)(out + (size_t)q * C + c) = m;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int regtr_rowsum_positive(const float* x, int n, int C, float* flag, void* stream)
+{
+    if (!x || !flag || n < 0 || C < 1) return RG_ERR_ARG;
+    if (n == 0) return RG_OK;
+    k_rowsum_positive<<<rg_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(x, n, C, flag);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
+int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
+                        int Cin, const float* flag, const float* kernel_points, int KP, float extent, float* wf,
+                        float* num, void* stream)
+{
+    if (!q_xyz || !s_xyz || !nbr || !x || !flag || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
+        Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f))
+        return RG_ERR_ARG;
+    if (nq == 0) return RG_OK;
+    GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, nq, ns, H, Cin, KP, extent};
+    hipStream_t st = (hipStream_t)stream;
+    const int LQ = Cin <= 16 ? 16 : (Cin <= 32 ? 32 : 64);
+    const int QW = RG_WAVE / LQ;
+    const size_t lds = (size_t)GATHER_WAVES * ((QW * H * (KP_PAD + 5) + 3) & ~3) * sizeof(float);
+    if (lds > 160 * 1024) return RG_ERR_ARG;
+    const int grid = rg_cdiv(nq, GATHER_WAVES * QW);
+    if (LQ == 16) k_kpconv_gather<16><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
+    else if (LQ == 32) k_kpconv_gather<32><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
+    else k_kpconv_gather<64><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream)
+{
+    if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || C < 4 || C % 4) return RG_ERR_ARG;
+    if (nq == 0) return RG_OK;
+    k_maxpool_gather<<<rg_cdiv(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, nq, H, out);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+}  // extern "C"

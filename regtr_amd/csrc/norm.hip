@@ -1,0 +1,223 @@
+// Normalisation / elementwise kernels of the RegTR hot path for gfx950 (all HBM-bound, float4 accesses):
+//   * per-cloud InstanceNorm (+ LeakyReLU 0.1, + residual) -- the reference's BatchNormBlock with
+//     nn.InstanceNorm1d: per cloud, per channel, biased variance, eps 1e-5, no affine
+//     (/root/reference/src/models/backbone_kpconv/kpconv_blocks.py:489,510-519,556-561,741)
+//   * LayerNorm (+ positional embedding add)   (models/transformer/transformers.py:194-195,213-215,232)
+//   * sine positional embedding                (models/transformer/position_embedding.py:29-50)
+// Statistics are accumulated in float64 with a fixed reduction tree, so results are run-to-run deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int IN_ROWS = 256;   // rows of one cloud handled by one workgroup
+
+// partial[(cloud * nchunk + chunk) * C + c] = (sum, sumsq) over the chunk's rows
+__global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
+                                                          int nchunk, double2* __restrict__ partial)
+{
+    __shared__ double sh[256 * 8];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
+    if (r0 >= r1) return;
+    const int C4 = C >> 2;
+    const int TC = C4 < 256 ? C4 : 256, TR = 256 / TC;
+    const int tx = threadIdx.x % TC, ty = threadIdx.x / TC;
+    for (int c4 = tx; c4 < C4; c4 += TC) {
+        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+        if (ty < TR)
+            for (int r = r0 + ty; r < r1; r += TR) {
+                const float4 v = *(const float4*)(x + (size_t)r * C + 4 * c4);
+                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+                ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sh[threadIdx.x * 8 + j] = s[j]; sh[threadIdx.x * 8 + 4 + j] = ss[j]; }
+        __syncthreads();
+        if (ty == 0) {
+            for (int y = 1; y < TR; y++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { s[j] += sh[(y * TC + tx) * 8 + j]; ss[j] += sh[(y * TC + tx) * 8 + 4 + j]; }
+            double2* o = partial + ((size_t)b * nchunk + chunk) * C + 4 * c4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = make_double2(s[j], ss[j]);
+        }
+    }
+}
+
+// stats[(cloud * C + c)] = (mean, 1/sqrt(var + eps))
+__global__ void __launch_bounds__(256) k_instnorm_finalize(const double2* __restrict__ partial, const int* __restrict__ seg_off,
+                                                           int C, int nchunk, float eps, float2* __restrict__ stats)
+{
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int n = seg_off[b + 1] - seg_off[b];
+    const int used = (n + IN_ROWS - 1) / IN_ROWS;
+    double s = 0, ss = 0;
+    for (int k = 0; k < used; k++) {
+        const double2 p = partial[((size_t)b * nchunk + k) * C + c];
+        s += p.x; ss += p.y;
+    }
+    float mean = 0.f, rstd = 0.f;
+    if (n > 0) {
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    stats[(size_t)b * C + c] = make_float2(mean, rstd);
+}
+
+// y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
+__global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
+                                                        const float2* __restrict__ stats, const float* __restrict__ res,
+                                                        const float2* __restrict__ res_stats, int act, float slope,
+                                                        float* __restrict__ y)
+{
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
+    if (r0 >= r1) return;
+    const int C4 = C >> 2;
+    const int total = (r1 - r0) * C4;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int r = r0 + e / C4, c = (e % C4) * 4;
+        float4 v = *(const float4*)(x + (size_t)r * C + c);
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (stats) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const float2 st = stats[(size_t)b * C + c + j]; o[j] = (o[j] - st.x) * st.y; }
+        }
+        if (res) {
+            const float4 rv = *(const float4*)(res + (size_t)r * C + c);
+            float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (res_stats) { const float2 st = res_stats[(size_t)b * C + c + j]; rr[j] = (rr[j] - st.x) * st.y; }
+                o[j] += rr[j];
+            }
+        }
+        if (act == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+        }
+        *(float4*)(y + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// one wave per row: y = LN(x) * gamma + beta (+ add)
+__global__ void __launch_bounds__(256) k_layernorm(const float* __restrict__ x, int n, int D, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, const float* __restrict__ add,
+                                                   float* __restrict__ y, float* __restrict__ y_plain)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = rg_lane();
+    const float* xr = x + (size_t)row * D;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += RG_WAVE * 4) {
+        const float4 v = *(const float4*)(xr + c);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mean = rg_wave_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += RG_WAVE * 4) {
+        const float4 v = *(const float4*)(xr + c);
+        const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+        ss += (a * a + b * b) + (cc * cc + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(rg_wave_sum(ss) / (float)D + eps);
+    for (int c = lane * 4; c < D; c += RG_WAVE * 4) {
+        const float4 v = *(const float4*)(xr + c);
+        const float4 gm = *(const float4*)(gamma + c), bt = *(const float4*)(beta + c);
+        float4 o = make_float4((v.x - mean) * rstd * gm.x + bt.x, (v.y - mean) * rstd * gm.y + bt.y,
+                               (v.z - mean) * rstd * gm.z + bt.z, (v.w - mean) * rstd * gm.w + bt.w);
+        if (y_plain) *(float4*)(y_plain + (size_t)row * D + c) = o;
+        if (add) {
+            const float4 a = *(const float4*)(add + (size_t)row * D + c);
+            o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        *(float4*)(y + (size_t)row * D + c) = o;
+    }
+}
+
+// pe[i, a*npf + f] = f even ? sin(xyz[i,a]*scale / dim_t[f]) : cos(...), zero padded to d_model
+__global__ void __launch_bounds__(256) k_posemb_sine(const float* __restrict__ xyz, int n, int npf, int d_model, float scale,
+                                                     const float* __restrict__ dim_t, float* __restrict__ pe)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * d_model) return;
+    const int i = (int)(e / d_model), d = (int)(e % d_model);
+    float v = 0.f;
+    if (d < 3 * npf) {
+        const int a = d / npf, f = d % npf;
+        const float p = __fdiv_rn(__fmul_rn(xyz[3 * (size_t)i + a], scale), dim_t[f]);
+        v = (f & 1) ? cosf(p) : sinf(p);
+    }
+    pe[e] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C)
+{
+    const size_t nchunk = (size_t)rg_cdiv(max_len > 0 ? max_len : 1, IN_ROWS);
+    return nchunk * n_clouds * C * sizeof(double2) + 256;
+}
+
+// stats [n_clouds, C, 2] = (mean, rstd) of x [N, C] per cloud segment.  max_len = longest segment (host-known bound).
+int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int max_len, int C, float eps, float* stats,
+                         void* ws, size_t ws_bytes, void* stream)
+{
+    if (!x || !seg_off || !stats || n_clouds < 1 || C < 4 || C % 4 || max_len < 0) return RG_ERR_ARG;
+    if (C > 1024 && (C / 4) % 256) return RG_ERR_ARG;
+    if (C / 4 < 256 && 256 % (C / 4)) return RG_ERR_ARG;
+    if (ws_bytes < regtr_instnorm_ws_bytes(n_clouds, max_len, C)) return RG_ERR_WORKSPACE;
+    if (max_len == 0) return RG_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = rg_cdiv(max_len, IN_ROWS);
+    k_instnorm_partial<<<dim3(nchunk, n_clouds), 256, 0, st>>>(x, seg_off, C, nchunk, (double2*)ws);
+    k_instnorm_finalize<<<dim3(rg_cdiv(C, 256), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, eps,
+                                                                         (float2*)stats);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// y = act( (x - mean) * rstd  [+ residual | + (residual - rmean) * rrstd] ), act 1 = LeakyReLU(slope).
+// stats may be NULL (x used as is).  y may alias x.
+int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int max_len, int C, const float* stats,
+                         const float* residual, const float* res_stats, int act, float slope, float* y, void* stream)
+{
+    if (!x || !seg_off || !y || n_clouds < 1 || C < 4 || C % 4 || max_len < 0) return RG_ERR_ARG;
+    if (max_len == 0) return RG_OK;
+    k_instnorm_apply<<<dim3(rg_cdiv(max_len, IN_ROWS), n_clouds), 256, 0, (hipStream_t)stream>>>(
+        x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// y = LayerNorm(x) * gamma + beta (+ add) ; y_plain (optional) receives the value before `add`.
+int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
+                    float* y, float* y_plain, void* stream)
+{
+    if (!x || !gamma || !beta || !y || n < 0 || D < 4 || D % 4) return RG_ERR_ARG;
+    if (n == 0) return RG_OK;
+    k_layernorm<<<rg_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(x, n, D, gamma, beta, eps, add, y, y_plain);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale, const float* dim_t, float* pe,
+                      void* stream)
+{
+    if (!xyz || !dim_t || !pe || n < 0 || npf < 1 || d_model < 3 * npf) return RG_ERR_ARG;
+    if (n == 0) return RG_OK;
+    k_posemb_sine<<<rg_cdiv((long long)n * d_model, 256), 256, 0, (hipStream_t)stream>>>(xyz, n, npf, d_model, scale,
+                                                                                          dim_t, pe);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+}  // extern "C"

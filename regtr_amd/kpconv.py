@@ -1,0 +1,266 @@
+"""KPConv preprocessing pyramid and encoder on the HIP kernels.
+
+Host-side mirror of /root/reference/src/models/backbone_kpconv/kpconv.py (Preprocessor :291-414 / PreprocessorGPU
+:417-537, KPFEncoder :22-88) and kpconv_blocks.py (SimpleBlock :590-646, ResnetBottleneckBlock :649-741, UnaryBlock
+:533-567, KPConv :175-414): same constructor arguments, same parameter names, same `kpconv_meta` dictionary.  All
+arithmetic is in libregtr_hip.so.
+
+Semantics are those of the reference's CPU ops (cpp_wrappers): voxel key floor((p - origin) / dl), neighbours
+distance-sorted then truncated to neighborhood_limits.  Documented differences, none of which changes a downstream
+value: neighbour tables always have K = neighborhood_limits[l] columns (the CPU path emits min(max_count, K),
+kpconv.py:255-258; extra columns are shadow indices), exact-distance ties are ordered by support index, subsampled
+rows are in first-appearance order, index tensors are int32 unless cfg.kpconv_meta_int64 is set, and the unused
+`upsamples` tables (kpconv.py:503-504; RegTR has no decoder) are left empty.
+"""
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kernel_points import load_kernels
+
+
+def _prepared(cache, key, param, fn):
+    """Weights re-laid-out for the kernels, cached until the parameter changes."""
+    ent = cache.get(key)
+    tag = (param.data_ptr(), param._version, param.device)
+    if ent is None or ent[0] != tag:
+        with torch.no_grad():
+            ent = (tag, fn(param.detach()))
+        cache[key] = ent
+    return ent[1]
+
+
+class Preprocessor(nn.Module):
+    """Computes the metadata used for KPConv (kpconv.py:291 / :417).  One host synchronisation per call: the whole
+    pyramid is enqueued against capacity-sized buffers, then the per-level segment offsets are read back once."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+
+    def forward(self, pts: List[torch.Tensor]):
+        cfg = self.cfg
+        limits = cfg.neighborhood_limits
+        device = pts[0].device
+        lens0 = [int(p.shape[0]) for p in pts]
+        n0 = sum(lens0)
+        n_clouds = len(pts)
+        points = torch.cat([p.to(torch.float32) for p in pts], dim=0).contiguous()
+        seg = torch.tensor(np.concatenate([[0], np.cumsum(lens0)]).astype(np.int32), device=device)
+
+        r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
+        layer_blocks, layer = [], 0
+        lv_points, lv_seg, lv_conv, lv_pool = [], [], [], []
+        cap = n0                                                              # N_{l+1} <= N_l <= N_0
+        arch = cfg.architecture
+        for block_i, block in enumerate(arch):                               # kpconv.py:328-404
+            if 'global' in block or 'upsample' in block:
+                break
+            if not ('pool' in block or 'strided' in block):
+                layer_blocks += [block]
+                if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
+                    continue
+            if any('deformable' in b for b in layer_blocks) or 'deformable' in block:
+                raise NotImplementedError('deformable KPConv is outside the RegTR inference path')
+            K = limits[layer]
+            grid = ops.CellGrid(points, seg, cap, r_normal)
+            conv_i = grid.query(points, seg, cap, K) if layer_blocks else None           # :349-351
+            if 'pool' in block or 'strided' in block:
+                dl = 2 * r_normal / cfg.conv_radius                                      # :363
+                pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)              # :366
+                pool_i = grid.query(pool_p, pool_seg, cap, K)                            # :376
+            else:
+                pool_p = pool_seg = pool_i = None
+            lv_points.append(points); lv_seg.append(seg); lv_conv.append(conv_i); lv_pool.append(pool_i)
+            points, seg = pool_p, pool_seg
+            r_normal *= 2
+            layer += 1
+            layer_blocks = []
+
+        # the one host round trip: level sizes
+        seg_host = torch.stack(lv_seg).cpu().numpy()                                     # (levels, n_clouds + 1)
+        data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
+                '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': []}
+        want64 = bool(cfg.get('kpconv_meta_int64', False))
+        for l in range(len(lv_points)):
+            n_l = int(seg_host[l, -1])
+            n_next = int(seg_host[l + 1, -1]) if l + 1 < len(lv_points) else 0
+            lens = np.diff(seg_host[l]).astype(np.int64)
+            data['_lens_host'].append(lens.tolist())
+            data['points'].append(lv_points[l][:n_l])
+            conv = lv_conv[l][:n_l] if lv_conv[l] is not None else torch.zeros((0, 1), dtype=torch.int32, device=device)
+            pool = lv_pool[l][:n_next] if lv_pool[l] is not None else torch.zeros((0, 1), dtype=torch.int32, device=device)
+            data['_neighbors_i32'].append(conv)
+            data['_pools_i32'].append(pool)
+            data['neighbors'].append(conv.long() if want64 else conv)
+            data['pools'].append(pool.long() if want64 else pool)
+            data['upsamples'].append(torch.zeros((0, 1), dtype=torch.int64, device=device))
+            data['stack_lengths'].append((lv_seg[l][1:] - lv_seg[l][:-1]).long())
+        return data
+
+
+PreprocessorGPU = Preprocessor   # the reference instantiates PreprocessorGPU (regtr.py:29); same contract here
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# blocks (parameter containers + HIP forward)
+# ----------------------------------------------------------------------------------------------------------------
+class KPConv(nn.Module):
+    """Parameters of kpconv_blocks.py:175-267 (non-deformable)."""
+
+    def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius, fixed_kernel_points='center',
+                 KP_influence='linear', aggregation_mode='sum', deformable=False, modulated=False):
+        super().__init__()
+        if deformable or KP_influence != 'linear' or aggregation_mode != 'sum':
+            raise NotImplementedError('only rigid KPConv with linear influence and sum aggregation is implemented '
+                                      '(the only mode either reference config uses)')
+        self.K, self.p_dim = kernel_size, p_dim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.KP_extent = radius, KP_extent
+        self.weights = nn.Parameter(torch.zeros((kernel_size, in_channels, out_channels), dtype=torch.float32))
+        nn.init.kaiming_uniform_(self.weights, a=5 ** 0.5)                      # kpconv_blocks.py:248-249
+        kp = load_kernels(radius, kernel_size, dimension=p_dim, fixed=fixed_kernel_points)
+        self.kernel_points = nn.Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)   # :266
+
+    def forward(self, q_pts, s_pts, neighb_inds, x):
+        w = self.weights.detach().view(self.K * self.in_channels, self.out_channels)
+        return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent)
+
+
+class UnaryBlock(nn.Module):
+    """Linear(no bias) -> per-cloud InstanceNorm -> LeakyReLU(0.1) (kpconv_blocks.py:533-567)."""
+
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super().__init__()
+        if not use_bn:
+            raise NotImplementedError('use_batch_norm=False (bias instead of InstanceNorm) is not implemented')
+        self.in_dim, self.out_dim, self.no_relu = in_dim, out_dim, no_relu
+        self.mlp = nn.Linear(in_dim, out_dim, bias=False)
+        self._cache = {}
+
+    def linear(self, x):
+        wt = _prepared(self._cache, 'w', self.mlp.weight, lambda w: w.t().contiguous())
+        return ops.gemm(x, wt)
+
+    def forward(self, x, seg_off, max_len):
+        y = self.linear(x)
+        st = ops.instnorm_stats(y, seg_off, max_len)
+        return ops.instnorm_apply(y, seg_off, max_len, st, lrelu=not self.no_relu, out=y)
+
+
+class _LevelView:
+    """What a block needs from kpconv_meta for its (possibly strided) convolution."""
+
+    def __init__(self, meta, layer, strided):
+        self.s_pts = meta['points'][layer]
+        self.q_pts = meta['points'][layer + 1] if strided else self.s_pts
+        self.inds = meta['_pools_i32'][layer] if strided else meta['_neighbors_i32'][layer]
+        self.seg_pre = meta['_seg_off'][layer]
+        self.max_pre = max(meta['_lens_host'][layer])
+        self.seg_post = meta['_seg_off'][layer + 1] if strided else self.seg_pre
+        self.max_post = max(meta['_lens_host'][layer + 1]) if strided else self.max_pre
+
+
+class SimpleBlock(nn.Module):
+    """KPConv -> InstanceNorm -> LeakyReLU (kpconv_blocks.py:590-646)."""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super().__init__()
+        current_extent = radius * config.KP_extent / config.conv_radius          # :603
+        self.block_name, self.layer_ind = block_name, layer_ind
+        self.KPConv = KPConv(config.num_kernel_points, config.in_points_dim, in_dim, out_dim // 2, current_extent,
+                             radius, fixed_kernel_points=config.fixed_kernel_points, KP_influence=config.KP_influence,
+                             aggregation_mode=config.aggregation_mode, deformable='deform' in block_name,
+                             modulated=config.modulated)
+        if not config.use_batch_norm:
+            raise NotImplementedError('use_batch_norm=False is not implemented')
+
+    def forward(self, x, meta):
+        v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
+        y = self.KPConv(v.q_pts, v.s_pts, v.inds, x)
+        st = ops.instnorm_stats(y, v.seg_post, v.max_post)
+        return ops.instnorm_apply(y, v.seg_post, v.max_post, st, lrelu=True, out=y)
+
+
+class ResnetBottleneckBlock(nn.Module):
+    """unary1 -> KPConv -> IN -> LReLU -> unary2 ; shortcut [max_pool][unary] ; LReLU(sum)
+    (kpconv_blocks.py:649-741)."""
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super().__init__()
+        current_extent = radius * config.KP_extent / config.conv_radius          # :662
+        bn, mom = config.use_batch_norm, config.batch_norm_momentum
+        self.block_name, self.layer_ind = block_name, layer_ind
+        self.unary1 = UnaryBlock(in_dim, out_dim // 4, bn, mom) if in_dim != out_dim // 4 else nn.Identity()
+        self.KPConv = KPConv(config.num_kernel_points, config.in_points_dim, out_dim // 4, out_dim // 4, current_extent,
+                             radius, fixed_kernel_points=config.fixed_kernel_points, KP_influence=config.KP_influence,
+                             aggregation_mode=config.aggregation_mode, deformable='deform' in block_name,
+                             modulated=config.modulated)
+        self.unary2 = UnaryBlock(out_dim // 4, out_dim, bn, mom, no_relu=True)
+        self.unary_shortcut = UnaryBlock(in_dim, out_dim, bn, mom, no_relu=True) if in_dim != out_dim else nn.Identity()
+
+    def forward(self, features, meta):
+        strided = 'strided' in self.block_name
+        v = _LevelView(meta, self.layer_ind, strided)
+        x = self.unary1(features, v.seg_pre, v.max_pre) if isinstance(self.unary1, UnaryBlock) else features   # :722
+        x = self.KPConv(v.q_pts, v.s_pts, v.inds, x)                                                          # :726
+        st = ops.instnorm_stats(x, v.seg_post, v.max_post)
+        x = ops.instnorm_apply(x, v.seg_post, v.max_post, st, lrelu=True, out=x)                              # :727
+        y = self.unary2.linear(x)                                                                             # :730
+        y_st = ops.instnorm_stats(y, v.seg_post, v.max_post)
+        shortcut = ops.maxpool(features, v.inds) if strided else features                                     # :734-737
+        sc_st = None
+        if isinstance(self.unary_shortcut, UnaryBlock):
+            shortcut = self.unary_shortcut.linear(shortcut)
+            sc_st = ops.instnorm_stats(shortcut, v.seg_post, v.max_post)
+        # LeakyReLU( IN(unary2) + [IN](shortcut) ) in one pass                                                :741
+        return ops.instnorm_apply(y, v.seg_post, v.max_post, y_st, residual=shortcut, res_stats=sc_st, lrelu=True, out=y)
+
+
+def block_decider(block_name, radius, in_dim, out_dim, layer_ind, config):
+    """kpconv_blocks.py:429-471, restricted to the block types of the RegTR encoders."""
+    if block_name in ('simple', 'simple_strided'):
+        return SimpleBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in ('resnetb', 'resnetb_strided'):
+        return ResnetBottleneckBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    raise NotImplementedError(f'block "{block_name}" is outside the RegTR inference path')
+
+
+class KPFEncoder(nn.Module):
+    """kpconv.py:22-88."""
+
+    def __init__(self, config, d_bottle, increase_channel_when_downsample=True):
+        super().__init__()
+        octave = 0
+        r = config.first_subsampling_dl * config.conv_radius
+        in_dim, out_dim = config.in_feats_dim, config.first_feats_dim
+        self.encoder_blocks = nn.ModuleList()
+        self.encoder_skip_dims, self.encoder_skips = [], []
+        block = None
+        for block_i, block in enumerate(config.architecture):
+            if any(t in block for t in ('pool', 'strided', 'upsample', 'global')):
+                self.encoder_skips.append(block_i)
+                self.encoder_skip_dims.append(in_dim)
+            if 'upsample' in block:
+                break
+            self.encoder_blocks.append(block_decider(block, r, in_dim, out_dim, octave, config))
+            in_dim = out_dim // 2 if 'simple' in block else out_dim
+            if 'pool' in block or 'strided' in block:
+                octave += 1
+                r *= 2
+                if increase_channel_when_downsample:
+                    out_dim *= 2
+        if 'upsample' not in block:
+            self.encoder_skips.append(block_i)
+            self.encoder_skip_dims.append(in_dim)
+
+    def forward(self, x, batch):
+        skip_x = []
+        for block_i, block_op in enumerate(self.encoder_blocks):
+            if block_i in self.encoder_skips:
+                skip_x.append(x)
+            x = block_op(x, batch)
+        return x, skip_x

@@ -1,0 +1,162 @@
+"""Tensor-level wrappers over the C ABI (include/regtr_hip.h).  torch is used for device memory and the current
+stream only; every arithmetic step runs in libregtr_hip.so.  Nothing here synchronises with the host."""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------------ preprocessing
+def grid_subsample(xyz, seg_off, n_cap, dl):
+    """xyz (n_cap,3) f32, seg_off (B+1,) i32 [device] -> (out_xyz (n_cap,3) [first out_seg_off[-1] rows live],
+    out_seg_off (B+1,) i32 [device]).  Row order: clouds stacked, voxels by first appearance."""
+    L = _lib.lib()
+    n_clouds = seg_off.numel() - 1
+    out = torch.empty((max(n_cap, 1), 3), dtype=torch.float32, device=xyz.device)
+    out_off = torch.empty(n_clouds + 1, dtype=torch.int32, device=xyz.device)
+    nb = L.regtr_grid_subsample_ws_bytes(n_cap, n_clouds)
+    ws = _ws(nb, xyz.device)
+    check(L.regtr_grid_subsample(ptr(xyz), ptr(seg_off), n_clouds, n_cap, float(dl), ptr(out), ptr(out_off),
+                                 ptr(ws), nb, stream()), 'regtr_grid_subsample')
+    return out, out_off
+
+
+class CellGrid:
+    """Support-point cell grid for one radius; serves any number of radius queries (conv + pool tables of a level)."""
+
+    def __init__(self, s_xyz, s_seg_off, ns_cap, radius):
+        L = _lib.lib()
+        self.n_clouds = s_seg_off.numel() - 1
+        self.s_seg_off, self.ns_cap, self.radius = s_seg_off, int(ns_cap), float(radius)
+        self.nbytes = L.regtr_cellgrid_ws_bytes(self.ns_cap, self.n_clouds)
+        self.ws = _ws(self.nbytes, s_xyz.device)
+        check(L.regtr_cellgrid_build(ptr(s_xyz), ptr(s_seg_off), self.n_clouds, self.ns_cap, self.radius, ptr(self.ws),
+                                     self.nbytes, stream()), 'regtr_cellgrid_build')
+
+    def query(self, q_xyz, q_seg_off, nq_cap, K, want_count=False):
+        L = _lib.lib()
+        idx = torch.empty((max(nq_cap, 1), K), dtype=torch.int32, device=q_xyz.device)
+        cnt = mx = None
+        if want_count:
+            cnt = torch.empty(max(nq_cap, 1), dtype=torch.int32, device=q_xyz.device)
+            mx = torch.zeros(1, dtype=torch.int32, device=q_xyz.device)
+        check(L.regtr_radius_query(ptr(q_xyz), ptr(q_seg_off), int(nq_cap), ptr(self.s_seg_off), self.ns_cap,
+                                   self.n_clouds, self.radius, int(K), ptr(self.ws), self.nbytes, ptr(idx), ptr(cnt),
+                                   ptr(mx), stream()), 'regtr_radius_query')
+        return (idx, cnt, mx) if want_count else idx
+
+
+# ------------------------------------------------------------------------------------------------ dense
+def gemm(a, b_kn, bias=None, row_div=None, residual=None, relu=False, out=None):
+    """a (M,K) @ b_kn (K,N) with the fused epilogue of regtr_gemm_f32.  `a` may be a row-strided view."""
+    M, K = a.shape
+    Kb, N = b_kn.shape
+    assert K == Kb and a.stride(1) == 1 and b_kn.is_contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    ldr = residual.stride(0) if residual is not None else 0
+    check(_lib.lib().regtr_gemm_f32(a.data_ptr(), a.stride(0) if M > 1 else K, ptr(b_kn), N, out.data_ptr(),
+                                    out.stride(0) if M > 1 else N, M, N, K, ptr(bias), ptr(row_div),
+                                    residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
+                                    stream()), 'regtr_gemm_f32')
+    return out
+
+
+def layernorm(x, gamma, beta, add=None, eps=1e-5, want_plain=False, out=None):
+    n, D = x.shape
+    y = torch.empty_like(x) if out is None else out
+    yp = torch.empty_like(x) if want_plain else None
+    check(_lib.lib().regtr_layernorm(ptr(x), n, D, ptr(gamma), ptr(beta), eps, ptr(add), ptr(y), ptr(yp), stream()),
+          'regtr_layernorm')
+    return (y, yp) if want_plain else y
+
+
+def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
+    """PositionEmbeddingCoordsSine.forward (position_embedding.py:29-50).  The 84-entry frequency table is
+    init-time constant data computed exactly the way the reference computes it (float32 pow)."""
+    n_dim = 3
+    npf = d_model // n_dim // 2 * 2
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = (temperature ** (2 * torch.div(dim_t, 2, rounding_mode='trunc') / npf)).to(xyz.device)
+    pe = torch.empty((xyz.shape[0], d_model), dtype=torch.float32, device=xyz.device)
+    scale32 = torch.tensor(scale * 2 * math.pi, dtype=torch.float32).item()
+    check(_lib.lib().regtr_posemb_sine(ptr(xyz), xyz.shape[0], npf, d_model, scale32, ptr(dim_t), ptr(pe), stream()),
+          'regtr_posemb_sine')
+    return pe
+
+
+# ------------------------------------------------------------------------------------------------ KPConv encoder
+def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent):
+    """KPConv.forward (kpconv_blocks.py:269-414), non-deformable / linear / sum.
+    nbr (Nq,H) i32, x (Ns,Cin), w_flat (KP*Cin, Cout) -> (Nq, Cout)."""
+    L = _lib.lib()
+    nq, H = nbr.shape
+    ns, Cin = x.shape
+    KP = kernel_points.shape[0]
+    dev = x.device
+    flag = torch.empty(ns, dtype=torch.float32, device=dev)
+    check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(flag), stream()), 'regtr_rowsum_positive')
+    wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
+    num = torch.empty(nq, dtype=torch.float32, device=dev)
+    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, ptr(nbr), H, ptr(x), Cin, ptr(flag),
+                                ptr(kernel_points), KP, float(extent), ptr(wf), ptr(num), stream()),
+          'regtr_kpconv_gather')
+    return gemm(wf, w_flat, row_div=num)
+
+
+def maxpool(x, nbr):
+    ns, C = x.shape
+    nq, H = nbr.shape
+    out = torch.empty((nq, C), dtype=torch.float32, device=x.device)
+    check(_lib.lib().regtr_maxpool_gather(ptr(x), ns, C, ptr(nbr), nq, H, ptr(out), stream()), 'regtr_maxpool_gather')
+    return out
+
+
+def instnorm_stats(x, seg_off, max_len, eps=1e-5):
+    L = _lib.lib()
+    n_clouds = seg_off.numel() - 1
+    C = x.shape[1]
+    stats = torch.empty((n_clouds, C, 2), dtype=torch.float32, device=x.device)
+    nb = L.regtr_instnorm_ws_bytes(n_clouds, max_len, C)
+    ws = _ws(nb, x.device)
+    check(L.regtr_instnorm_stats(ptr(x), ptr(seg_off), n_clouds, int(max_len), C, eps, ptr(stats), ptr(ws), nb,
+                                 stream()), 'regtr_instnorm_stats')
+    return stats
+
+
+def instnorm_apply(x, seg_off, max_len, stats, residual=None, res_stats=None, lrelu=False, slope=0.1, out=None):
+    n_clouds = seg_off.numel() - 1
+    C = x.shape[1]
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().regtr_instnorm_apply(ptr(x), ptr(seg_off), n_clouds, int(max_len), C, ptr(stats), ptr(residual),
+                                          ptr(res_stats), 1 if lrelu else 0, slope, ptr(out), stream()),
+          'regtr_instnorm_apply')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention + pose
+def mha(q, k, v, seg_off, kv_of, max_len, n_heads):
+    """q, k, v: (N, E) column views of a packed projection; returns (N, E) concatenated heads."""
+    N, E = q.shape
+    hd = E // n_heads
+    out = torch.empty((N, E), dtype=torch.float32, device=q.device)
+    check(_lib.lib().regtr_mha_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                   ptr(out), E, ptr(seg_off), ptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
+                                   1.0 / math.sqrt(hd), stream()), 'regtr_mha_fwd')
+    return out
+
+
+def weighted_procrustes(kp, corr, logit, seg_off, n_pairs):
+    """kp (N,3), corr (L,N,3), logit (L,N), seg_off (2B+1,) i32 -> pose (L,B,3,4)."""
+    Lyr, N = logit.shape
+    pose = torch.empty((Lyr, n_pairs, 3, 4), dtype=torch.float32, device=kp.device)
+    check(_lib.lib().regtr_weighted_procrustes(ptr(kp), ptr(corr), ptr(logit), ptr(seg_off), n_pairs, N, Lyr, ptr(pose),
+                                               stream()), 'regtr_weighted_procrustes')
+    return pose

@@ -1,0 +1,168 @@
+"""REGTR network, inference forward, on the MI355X HIP kernels.
+
+Drop-in for the reference's `RegTR` (/root/reference/src/models/regtr.py:22-235): same constructor (`RegTR(cfg)`),
+same `forward(batch) -> dict` contract (input lists batch['src_xyz'] / batch['tgt_xyz'], side effect
+batch['kpconv_meta'], output keys of regtr.py:218-235), same `state_dict` names and shapes, so a reference checkpoint
+loads with `load_state_dict(state['state_dict'])` (demo.py:165).  Training-only members (compute_loss, criteria) are
+not implemented; their parameters (`feature_criterion.W`, feature_loss.py:261) are kept so strict loading works.
+
+The forward enqueues every stage on the current HIP stream with ONE host synchronisation (the data-dependent level
+sizes after preprocessing): preprocess -> KPConv encoder -> feat_proj -> 6 cross-encoder layers on packed tokens ->
+correspondence head -> fused weighted-Procrustes.
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import as_config
+from .kpconv import KPFEncoder, PreprocessorGPU, _prepared
+from .transformer import TransformerCrossEncoder, TransformerCrossEncoderLayer
+
+_TIMEIT = False   # reference: regtr.py:19 -- stage timer (preprocess / encoder / attention+head / pose / total)
+
+
+class PositionEmbeddingCoordsSine(nn.Module):
+    """position_embedding.py:7-50 (parameter free)."""
+
+    def __init__(self, n_dim=1, d_model=256, temperature=10000, scale=None):
+        super().__init__()
+        if n_dim != 3:
+            raise NotImplementedError
+        self.n_dim, self.d_model, self.temperature = n_dim, d_model, temperature
+        self.scale = 1.0 if scale is None else scale
+
+    def forward(self, xyz):
+        return ops.posemb_sine(xyz, self.d_model, self.scale, self.temperature)
+
+
+class CorrespondenceRegressor(nn.Module):
+    """regtr.py:399-443: coor_mlp (D->D->D->3, ReLU) and conf_logits_decoder (D->1)."""
+
+    def __init__(self, d_embed):
+        super().__init__()
+        self.coor_mlp = nn.Sequential(nn.Linear(d_embed, d_embed), nn.ReLU(), nn.Linear(d_embed, d_embed), nn.ReLU(),
+                                      nn.Linear(d_embed, 3))
+        self.conf_logits_decoder = nn.Linear(d_embed, 1)
+        self._cache = {}
+
+    def forward(self, feats):
+        """feats (L, N, D) -> corr (L, N, 3), logit (L, N)."""
+        Lyr, N, D = feats.shape
+        f = feats.view(Lyr * N, D)
+        wt = lambda k, lin: _prepared(self._cache, k, lin.weight, lambda w: w.t().contiguous())
+        h = ops.gemm(f, wt('0', self.coor_mlp[0]), bias=self.coor_mlp[0].bias.detach(), relu=True)
+        h = ops.gemm(h, wt('2', self.coor_mlp[2]), bias=self.coor_mlp[2].bias.detach(), relu=True)
+        corr = ops.gemm(h, wt('4', self.coor_mlp[4]), bias=self.coor_mlp[4].bias.detach())
+        logit = ops.gemm(f, wt('c', self.conf_logits_decoder), bias=self.conf_logits_decoder.bias.detach())
+        return corr.view(Lyr, N, 3), logit.view(Lyr, N)
+
+
+class _LossParams(nn.Module):
+    """Holds InfoNCELossFull.W (feature_loss.py:261) so reference checkpoints load strictly; never used at inference."""
+
+    def __init__(self, d_embed):
+        super().__init__()
+        self.W = nn.Parameter(torch.zeros(d_embed, d_embed), requires_grad=False)
+
+
+class RegTR(nn.Module):
+    def __init__(self, cfg, *args, **kwargs):
+        super().__init__()
+        cfg = as_config(cfg)
+        self.cfg = cfg
+        self.logger = logging.getLogger(self.__class__.__name__)
+        self.preprocessor = PreprocessorGPU(cfg)                                  # regtr.py:29
+        self.kpf_encoder = KPFEncoder(cfg, cfg.d_embed)                           # :34
+        self.feat_proj = nn.Linear(self.kpf_encoder.encoder_skip_dims[-1], cfg.d_embed, bias=True)   # :36
+        if cfg.get('pos_emb_type', 'sine') == 'sine':                             # :41-47
+            self.pos_embed = PositionEmbeddingCoordsSine(3, cfg.d_embed, scale=cfg.get('pos_emb_scaling', 1.0))
+        else:
+            raise NotImplementedError('only the sine positional embedding of the shipped configs is implemented')
+        encoder_layer = TransformerCrossEncoderLayer(                             # :52-59
+            cfg.d_embed, cfg.nhead, cfg.d_feedforward, cfg.dropout, activation=cfg.transformer_act,
+            normalize_before=cfg.pre_norm, sa_val_has_pos_emb=cfg.sa_val_has_pos_emb,
+            ca_val_has_pos_emb=cfg.ca_val_has_pos_emb, attention_type=cfg.attention_type)
+        encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
+        self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
+                                                           return_intermediate=True)
+        if cfg.get('direct_regress_coor', False):                                 # :68-73
+            self.correspondence_decoder = CorrespondenceRegressor(cfg.d_embed)
+        else:
+            raise NotImplementedError('the attention CorrespondenceDecoder (direct_regress_coor: False) is not implemented; '
+                                      'both shipped configs regress coordinates with the MLP head')
+        if cfg.get('feature_loss_type', 'infonce') == 'infonce':                  # :79-81
+            self.feature_criterion = _LossParams(cfg.d_embed)
+            self.feature_criterion_un = _LossParams(cfg.d_embed)
+        self._cache = {}
+        self.last_timings = None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @torch.no_grad()
+    def forward(self, batch):
+        B = len(batch['src_xyz'])
+        dev = batch['src_xyz'][0].device
+        if dev.type != 'cuda':
+            raise RuntimeError('regtr_amd.RegTR runs on an MI355X (HIP) device only; there is no CPU path')
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if _TIMEIT else None
+        if ev: ev[0].record()
+
+        # ---- preprocess (regtr.py:117-122)
+        kpconv_meta = self.preprocessor(batch['src_xyz'] + batch['tgt_xyz'])
+        batch['kpconv_meta'] = kpconv_meta
+        slens_c = kpconv_meta['_lens_host'][-1]
+        src_slens_c, tgt_slens_c = slens_c[:B], slens_c[B:]
+        feats0 = torch.ones_like(kpconv_meta['points'][0][:, 0:1])
+        if ev: ev[1].record()
+
+        # ---- KPConv encoder (regtr.py:136)
+        feats_un, _ = self.kpf_encoder(feats0, kpconv_meta)
+        if ev: ev[2].record()
+
+        # ---- projection, positional embedding, cross-encoder on packed tokens (regtr.py:145-166)
+        wt = _prepared(self._cache, 'feat_proj', self.feat_proj.weight, lambda w: w.t().contiguous())
+        both_feats_un = ops.gemm(feats_un, wt, bias=self.feat_proj.bias.detach())
+        xyz_c = kpconv_meta['points'][-1]
+        seg_c = kpconv_meta['_seg_off'][-1]
+        pe = self.pos_embed(xyz_c) if self.cfg.transformer_encoder_has_pos_emb else None
+        kv_self = _prepared(self._cache, ('kv_self', B, dev), self.feat_proj.bias,
+                            lambda _: torch.arange(2 * B, dtype=torch.int32, device=dev))
+        kv_cross = _prepared(self._cache, ('kv_cross', B, dev), self.feat_proj.bias,
+                             lambda _: torch.cat([torch.arange(B, 2 * B), torch.arange(0, B)]).to(torch.int32).to(dev))
+        feats_cond = self.transformer_encoder(both_feats_un, pe, seg_c, kv_self, kv_cross, max(slens_c))   # (L, N, D)
+
+        # ---- correspondence head (regtr.py:168) and pose (regtr.py:185-203)
+        corr, logit = self.correspondence_decoder(feats_cond)
+        if ev: ev[3].record()
+        pose = ops.weighted_procrustes(xyz_c, corr, logit, seg_c, B)
+        if ev:
+            ev[4].record()
+            torch.cuda.synchronize()
+            self.last_timings = {'preprocess': ev[0].elapsed_time(ev[1]) / 1e3, 'encoder': ev[1].elapsed_time(ev[2]) / 1e3,
+                                 'attention': ev[2].elapsed_time(ev[3]) / 1e3, 'pose': ev[3].elapsed_time(ev[4]) / 1e3,
+                                 'total': ev[0].elapsed_time(ev[4]) / 1e3}
+
+        # ---- unpack into the reference's per-pair lists (views, no copies)
+        off = [0]
+        for n in slens_c:
+            off.append(off[-1] + n)
+        sl = lambda c: slice(off[c], off[c + 1])
+        logit3 = logit.unsqueeze(-1)
+        outputs = {
+            'src_feat_un': tuple(both_feats_un[sl(b)] for b in range(B)),
+            'tgt_feat_un': tuple(both_feats_un[sl(B + b)] for b in range(B)),
+            'src_feat': [feats_cond[:, sl(b)] for b in range(B)],          # List(B) of (N_pred, N_src, D)
+            'tgt_feat': [feats_cond[:, sl(B + b)] for b in range(B)],
+            'src_kp': tuple(xyz_c[sl(b)] for b in range(B)),
+            'src_kp_warped': [corr[:, sl(b)] for b in range(B)],
+            'tgt_kp': tuple(xyz_c[sl(B + b)] for b in range(B)),
+            'tgt_kp_warped': [corr[:, sl(B + b)] for b in range(B)],
+            'src_overlap': [logit3[:, sl(b)] for b in range(B)],
+            'tgt_overlap': [logit3[:, sl(B + b)] for b in range(B)],
+            'pose': pose,
+        }
+        return outputs

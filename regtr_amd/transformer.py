@@ -1,0 +1,96 @@
+"""Cross-encoder transformer on the HIP kernels.
+
+Host-side mirror of /root/reference/src/models/transformer/transformers.py (TransformerCrossEncoderLayer :84-258,
+forward_pre :183-244; TransformerCrossEncoder :18-59) with identical parameter names.  The reference pads the two
+clouds of each pair to (N_max, B, D) and masks; here every token of every cloud lives in one PACKED (N_total, D)
+array with device-side segment offsets, so the shared-weight self-attention of src and tgt, both directions of the
+cross-attention and the FFN each become ONE launch over all tokens of the batch.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .kpconv import _prepared
+
+
+class TransformerCrossEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation='relu', normalize_before=False,
+                 sa_val_has_pos_emb=False, ca_val_has_pos_emb=False, attention_type='dot_prod'):
+        super().__init__()
+        if attention_type != 'dot_prod':
+            raise NotImplementedError                                             # transformers.py:94-98
+        if activation != 'relu':
+            raise NotImplementedError('only the ReLU feed-forward of the shipped configs is implemented')
+        if not normalize_before:
+            raise NotImplementedError('forward_post (pre_norm: False) is not implemented; both shipped configs use pre_norm')
+        if dropout != 0.0:
+            raise NotImplementedError('inference path: dropout must be 0 (as in both shipped configs)')
+        # parameter containers with the reference's names; their torch forward is never called
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.nhead, self.d_model = nhead, d_model
+        self.sa_val_has_pos_emb, self.ca_val_has_pos_emb = sa_val_has_pos_emb, ca_val_has_pos_emb
+        self._cache = {}
+
+    def _wt(self, name, param):
+        return _prepared(self._cache, name, param, lambda w: w.t().contiguous())
+
+    def _attention(self, attn, tag, x, norm, pe, val_has_pe, seg_off, kv_of, max_len):
+        """x + out_proj( MHA(q = k = LN(x) + pe, v = LN(x) [+ pe]) ) for every token (transformers.py:194-229)."""
+        D = self.d_model
+        w_in = self._wt(tag + '_in', attn.in_proj_weight)                      # (D, 3D)
+        b_in = attn.in_proj_bias.detach()
+        if pe is None:
+            x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), eps=norm.eps)
+            qkv = ops.gemm(x2p, w_in, bias=b_in)
+        elif val_has_pe:
+            x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps)
+            qkv = ops.gemm(x2p, w_in, bias=b_in)
+        else:
+            x2p, x2 = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps, want_plain=True)
+            qkv = torch.empty((x.shape[0], 3 * D), dtype=torch.float32, device=x.device)
+            ops.gemm(x2p, w_in[:, :2 * D].contiguous(), bias=b_in[:2 * D].contiguous(), out=qkv[:, :2 * D])
+            ops.gemm(x2, w_in[:, 2 * D:].contiguous(), bias=b_in[2 * D:].contiguous(), out=qkv[:, 2 * D:])
+        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
+        return ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
+
+    def forward(self, x, pe, seg_off, kv_self, kv_cross, max_len):
+        """x: (N_total, D) tokens of all clouds [src_0..src_{B-1}, tgt_0..tgt_{B-1}]."""
+        x = self._attention(self.self_attn, 'sa', x, self.norm1, pe, self.sa_val_has_pos_emb, seg_off, kv_self, max_len)
+        x = self._attention(self.multihead_attn, 'ca', x, self.norm2, pe, self.ca_val_has_pos_emb, seg_off, kv_cross,
+                            max_len)
+        x2 = ops.layernorm(x, self.norm3.weight.detach(), self.norm3.bias.detach(), eps=self.norm3.eps)   # :232
+        h = ops.gemm(x2, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
+        return ops.gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)  # :233-238
+
+
+class TransformerCrossEncoder(nn.Module):
+    def __init__(self, cross_encoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(cross_encoder_layer) for _ in range(num_layers)])   # :268-269
+        self.num_layers, self.norm, self.return_intermediate = num_layers, norm, return_intermediate
+
+    def forward(self, x, pe, seg_off, kv_self, kv_cross, max_len):
+        """-> (L, N_total, D) if return_intermediate else (1, N_total, D)   (transformers.py:37-59)."""
+        n_out = self.num_layers if self.return_intermediate else 1
+        outs = torch.empty((n_out,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        for li, layer in enumerate(self.layers):
+            x = layer(x, pe, seg_off, kv_self, kv_cross, max_len)
+            if self.return_intermediate:
+                self._final(x, outs[li])
+        if not self.return_intermediate:
+            self._final(x, outs[0])
+        return outs
+
+    def _final(self, x, out):
+        if self.norm is None:
+            out.copy_(x)
+        else:
+            ops.layernorm(x, self.norm.weight.detach(), self.norm.bias.detach(), eps=self.norm.eps, out=out)

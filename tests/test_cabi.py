@@ -1,0 +1,110 @@
+"""CPU: the C-ABI library loads and exports exactly what include/regtr_hip.h declares; host-side contracts."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT, load_cfg, seeded_sd
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, 'include', 'regtr_hip.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(regtr_\w+)\s*\(', txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from regtr_amd import _lib
+    lib = _lib.lib()
+    names = _header_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/regtr_hip.h but not exported'
+    assert sorted(_lib.SIGNATURES) == names, 'ctypes signatures and header disagree'
+
+
+def test_workspace_size_queries_are_host_only():
+    from regtr_amd import _lib
+    lib = _lib.lib()
+    a, b = lib.regtr_grid_subsample_ws_bytes(1000, 2), lib.regtr_grid_subsample_ws_bytes(100000, 2)
+    assert 0 < a < b
+    assert lib.regtr_cellgrid_ws_bytes(50000, 4) > lib.regtr_cellgrid_ws_bytes(500, 4) > 0
+    assert lib.regtr_instnorm_ws_bytes(2, 20000, 128) >= 2 * 79 * 128 * 16
+
+
+def test_argument_errors_return_status_not_crash():
+    from regtr_amd import _lib
+    lib = _lib.lib()
+    assert lib.regtr_gemm_f32(None, 4, None, 4, None, 4, 1, 4, 4, None, None, None, 0, 0, None) == -2
+    assert lib.regtr_radius_query(None, None, 1, None, 1, 1, 0.1, 40, None, 0, None, None, None, None) == -2
+    assert lib.regtr_grid_subsample(None, None, 1, 1, 0.1, None, None, None, 0, None) == -2
+    with pytest.raises(RuntimeError):
+        _lib.check(-3, 'x')
+
+
+@pytest.mark.parametrize('name', ['3dmatch', 'modelnet'])
+def test_state_dict_contract(name):
+    """Parameter names / shapes equal the reference's (cross-checked against the real reference
+    module in oracle/make_golden.py) and a reference-style checkpoint loads strictly (demo.py:165)."""
+    from regtr_amd import RegTR
+    from oracle.seeded_weights import param_shapes
+    cfg = load_cfg(name)
+    m = RegTR(cfg)
+    sd = m.state_dict()
+    ref = param_shapes(cfg)
+    assert list(sd.keys()) == list(ref.keys())
+    for k, s in ref.items():
+        assert tuple(sd[k].shape) == tuple(s), k
+    m.load_state_dict(seeded_sd(cfg), strict=True)
+    assert sum(p.numel() for p in m.parameters()) == (11845811 if name == '3dmatch' else 11488018)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU instead of silently computing somewhere else."""
+    from regtr_amd import RegTR, ops
+    cfg = load_cfg('modelnet')
+    m = RegTR(cfg)
+    batch = {'src_xyz': [torch.rand(50, 3)], 'tgt_xyz': [torch.rand(60, 3)]}
+    with pytest.raises(RuntimeError):
+        m(batch)
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.rand(4, 4), torch.rand(4, 4))
+
+
+def test_product_never_imports_oracle():
+    import ast
+    pkg = os.path.join(ROOT, 'regtr_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            tree = ast.parse(open(os.path.join(pkg, fn)).read())
+            for node in ast.walk(tree):
+                mods = []
+                if isinstance(node, ast.Import):
+                    mods = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    mods = [node.module or '']
+                assert not any(m.split('.')[0] == 'oracle' for m in mods), f'{fn} imports oracle'
+
+
+def test_config_contract(tmp_path):
+    from regtr_amd.config import load_config
+    p = tmp_path / 'c.yaml'
+    p.write_text('a:\n  x: 1\n  y: [1, 2]\nb:\n  z: hello\n')
+    cfg = load_config(str(p))
+    assert cfg.x == 1 and cfg['y'] == [1, 2] and cfg.get('q', 5) == 5 and 'z' in cfg   # utils/misc.py:24-27 flattening
+
+
+def test_kernel_points_loader_matches_reference_recipe():
+    from regtr_amd.kernel_points import K015_CENTER, load_kernels
+    np.random.seed(0)
+    kp = load_kernels(0.0625, 15, 3, 'center')
+    assert kp.shape == (15, 3) and kp.dtype == np.float32
+    np.random.seed(0)
+    th = np.random.rand() * 2 * np.pi
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+    exp = np.matmul(0.0625 * (K015_CENTER + np.random.normal(scale=0.01, size=(15, 3))), R).astype(np.float32)
+    assert np.array_equal(kp, exp)
+    assert np.allclose(np.linalg.norm(K015_CENTER[1:], axis=1).mean(), 0.66, atol=0.02)

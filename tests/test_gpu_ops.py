@@ -1,0 +1,291 @@
+"""GPU (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle on the same seeded inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import gold, load_cfg, seeded_sd, seg_of, synth_cloud, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from regtr_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------------------------------------ GEMM / MFMA layout
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric B catches any row/col swap in the MFMA fragment or accumulator layout."""
+    ops = _ops()
+    n = 96
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) * 0.5 + torch.arange(n, dtype=torch.float32)[:, None] * 7
+    out = ops.gemm(torch.eye(n).cuda(), b.cuda())
+    assert torch.equal(out.cpu(), b)
+
+
+@pytest.mark.parametrize('M,N,K', [(751, 256, 256), (38061, 32, 480), (1000, 3, 256), (777, 1, 256), (513, 64, 15),
+                                   (64, 64, 16), (1, 768, 256), (2753, 512, 128), (130, 1024, 3840)])
+def test_gemm_vs_fp64(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g); b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g); div = torch.randint(1, 40, (M,), generator=g).float(); res = torch.randn(M, N, generator=g)
+    ref = (a.double() @ b.double())
+    out = ops.gemm(a.cuda(), b.cuda()).cpu()
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-6
+    assert (out.double() - ref).abs().max() < tol * max(1.0, ref.abs().max().item() / 10)
+    ref2 = torch.relu(ref / div[:, None].double() + bias.double()) + res.double()
+    out2 = ops.gemm(a.cuda(), b.cuda(), bias=bias.cuda(), row_div=div.cuda(), residual=res.cuda(), relu=True).cpu()
+    assert (out2.double() - ref2).abs().max() < tol * max(1.0, ref.abs().max().item() / 10)
+
+
+def test_gemm_strided_views():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn(300, 768, generator=g).cuda()
+    w = torch.randn(256, 512, generator=g).cuda()
+    out = torch.zeros(300, 768).cuda()
+    ops.gemm(big[:, 256:512], w, out=out[:, :512])
+    ref = big[:, 256:512].cpu().double() @ w.cpu().double()
+    assert (out[:, :512].cpu().double() - ref).abs().max() < 2e-4
+    assert out[:, 512:].abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ preprocessing
+def _check_subsample(pts, lens, dl):
+    from oracle import native
+    ops = _ops()
+    n = len(pts)
+    out, out_seg = ops.grid_subsample(to_dev(pts), seg_of(lens), n, dl)
+    oseg = out_seg.cpu().numpy()
+    ref_p, ref_l = native.grid_subsample(pts, np.asarray(lens, np.int32), dl)
+    assert np.array_equal(np.diff(oseg), ref_l)
+    got = out[:oseg[-1]].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref_p.view(np.uint32)), 'barycentres / order not bit exact'
+    return got, np.diff(oseg).astype(np.int32)
+
+
+def _check_radius(q, ql, s, sl, r, K):
+    from oracle import native
+    ops = _ops()
+    grid = ops.CellGrid(to_dev(s), seg_of(sl), len(s), r)
+    idx, cnt, mx = grid.query(to_dev(q), seg_of(ql), len(q), K, want_count=True)
+    ref_idx, ref_cnt, _ = native.radius_neighbors(q, s, np.asarray(ql, np.int32), np.asarray(sl, np.int32), r, K)
+    assert np.array_equal(cnt[:len(q)].cpu().numpy(), ref_cnt)
+    assert int(mx.item()) == (ref_cnt.max() if len(q) else 0)
+    assert np.array_equal(idx[:len(q)].cpu().numpy(), ref_idx), 'neighbour indices not bit exact'
+    return idx[:len(q)]
+
+
+@pytest.mark.parametrize('case', ['modelnet', '3dmatch_crop'])
+def test_preprocess_native_fixture(case):
+    g = gold(f'native_{case}')
+    pts, lens, dl, r = g['pts'], g['lens'], float(g['dl']), float(g['radius'])
+    sub, sub_l = _check_subsample(pts, lens, dl)
+    _check_radius(pts, lens, pts, lens, r, 40)
+    _check_radius(sub, sub_l, pts, lens, r, 40)
+    _check_radius(pts, lens, pts, lens, r, 7)        # heavy truncation
+    # product barycentres == the unmodified reference's, as multisets (row order is the documented difference)
+    o = 0
+    for n in sub_l:
+        a, b = sub[o:o + n], g['sub_pts'][o:o + n]
+        assert np.array_equal(a[np.lexsort(a.T[::-1])].view(np.uint32), b[np.lexsort(b.T[::-1])].view(np.uint32))
+        o += n
+
+
+def test_preprocess_full_pyramid_kitchen():
+    """3DMatch-sized real pair: every level's points and both neighbour tables bit exact vs the oracle."""
+    g = gold('3dmatch_kitchen')
+    pts = np.concatenate([g['src'], g['tgt']]); lens = np.array([len(g['src']), len(g['tgt'])], np.int32)
+    dl, r = 0.05, 0.0625
+    for level in range(4):
+        _check_radius(pts, lens, pts, lens, r, 40)
+        if level == 3:
+            break
+        sub, sub_l = _check_subsample(pts, lens, dl)
+        assert np.array_equal(sub_l, g[f'lens_{level + 1}'])       # same voxel counts as the reference
+        _check_radius(sub, sub_l, pts, lens, r, 40)
+        pts, lens, dl, r = sub, sub_l, dl * 2, r * 2
+
+
+def test_preprocess_edge_cases():
+    rng = np.random.default_rng(11)
+    # ragged batch incl. an EMPTY cloud, a single-point cloud, exact-tie lattice data, negative coordinates
+    clouds = [synth_cloud(rng, 700, lattice=0.01) - 3.0, np.zeros((0, 3), np.float32), synth_cloud(rng, 1, 0.1),
+              synth_cloud(rng, 1300, lattice=0.006) + 5.0]
+    pts = np.concatenate(clouds); lens = np.array([len(c) for c in clouds], np.int32)
+    sub, sub_l = _check_subsample(pts, lens, 0.05)
+    _check_radius(pts, lens, pts, lens, 0.0625, 40)
+    _check_radius(sub, sub_l, pts, lens, 0.0625, 40)
+    # all points in one voxel / one ball: long member lists, > 256 candidates (LDS list shrink path), K > count
+    dense = (rng.uniform(0, 0.03, (900, 3))).astype(np.float32)
+    _check_subsample(dense, [900], 0.05)
+    _check_radius(dense, [900], dense, [900], 0.06, 40)
+    _check_radius(dense, [900], dense, [900], 0.06, 300)
+    _check_radius(dense[:5], [5], dense, [900], 1e-4, 16)     # mostly empty rows -> all padding
+    # duplicates: identical points tie at d2 = 0 -> index order
+    dup = np.repeat(synth_cloud(rng, 50), 3, axis=0)
+    _check_radius(dup, [150], dup, [150], 0.1, 40)
+
+
+def test_preprocess_large_random_sizes():
+    rng = np.random.default_rng(5)
+    clouds = [synth_cloud(rng, n, extent=3.0) for n in (20000, 23000)]
+    pts = np.concatenate(clouds); lens = np.array([len(c) for c in clouds], np.int32)
+    # size-independent properties at full size (the oracle's brute force is checked on a slice)
+    ops = _ops()
+    out, out_seg = ops.grid_subsample(to_dev(pts), seg_of(lens), len(pts), 0.05)
+    oseg = out_seg.cpu().numpy()
+    sub = out[:oseg[-1]].cpu().numpy()
+    # idempotence-like: every barycentre lies in its own voxel -> subsampling the result at the same dl keeps counts
+    grid = ops.CellGrid(to_dev(pts), seg_of(lens), len(pts), 0.0625)
+    idx = grid.query(to_dev(pts), seg_of(lens), len(pts), 40).cpu().numpy()
+    assert np.array_equal(idx[:, 0], np.arange(len(pts)))               # self is the nearest neighbour
+    valid = idx < len(pts)
+    nb = np.where(valid, idx, 0)
+    d = np.linalg.norm(pts[nb] - pts[:, None], axis=2)
+    assert (d[valid] < 0.0625 + 1e-6).all()
+    dd = np.where(valid, d, np.inf)
+    assert (np.diff(dd, axis=1)[valid[:, 1:]] >= -1e-7).all()           # sorted by distance
+    cl = (idx[:, 0] >= lens[0]).astype(int)
+    assert ((np.where(valid, idx, -1) >= lens[0]) == (cl[:, None] == 1))[valid].all()   # never crosses clouds
+    sl = slice(0, 3000)
+    from oracle import native
+    ref, _, _ = native.radius_neighbors(pts[sl], pts, np.array([3000, 0], np.int32), lens, 0.0625, 40)
+    assert np.array_equal(idx[sl], ref)
+    assert len(sub) == native.grid_subsample(pts, lens, 0.05)[0].shape[0]
+
+
+def test_cpp_wrappers_dropin():
+    """numpy-level drop-in of cpp_subsampling.subsample_batch / cpp_neighbors.batch_query (kpconv.py:176,254)."""
+    from oracle import native
+    from regtr_amd.cpp_wrappers import grid_subsampling, radius_neighbors
+    g = gold('native_modelnet')
+    pts, lens = g['pts'], g['lens']
+    s_pts, s_len = grid_subsampling.subsample_batch(pts, lens, sampleDl=float(g['dl']), max_p=0, verbose=0)
+    assert s_pts.dtype == np.float32 and s_len.dtype == np.int32 and np.array_equal(s_len, g['sub_lens'])
+    nb = radius_neighbors.batch_query(pts, pts, lens, lens, radius=float(g['radius']))
+    assert nb.dtype == np.int32 and nb.shape == g['neighbors'].shape      # same untruncated width as the reference
+    ref, _, _ = native.radius_neighbors(pts, pts, lens, lens, float(g['radius']), nb.shape[1])
+    assert np.array_equal(nb, ref)
+    with pytest.raises(RuntimeError):
+        radius_neighbors.batch_query(pts[:, :2], pts, lens, lens, radius=0.1)
+
+
+# ------------------------------------------------------------------------------------------------ encoder kernels
+@pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40)])
+def test_kpconv_vs_oracle(Cin, Cout, H):
+    from oracle import native, regtr_ref
+    from regtr_amd.kernel_points import K015_CENTER
+    ops = _ops()
+    rng = np.random.default_rng(Cin)
+    s = synth_cloud(rng, 1500); q = s[::3].copy()
+    r = 0.12
+    idx, _, _ = native.radius_neighbors(q, s, np.array([len(q)], np.int32), np.array([len(s)], np.int32), r, H)
+    x = rng.standard_normal((len(s), Cin)).astype(np.float32)
+    x[rng.random(len(s)) < 0.2] *= -1.0            # some supports with negative feature sums (normaliser)
+    if Cin == 1:
+        x[:] = 1.0
+    w = (rng.standard_normal((15, Cin, Cout)) / math.sqrt(Cin * 15)).astype(np.float32)
+    kp = (K015_CENTER * r).astype(np.float32)
+    extent = r * 2.0 / 2.5
+    ref = regtr_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64)),
+                           torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(kp), extent)
+    out = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), to_dev(x), to_dev(w.reshape(15 * Cin, Cout)), to_dev(kp), extent)
+    assert (out.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_maxpool_instnorm_vs_oracle():
+    from oracle import native, regtr_ref
+    ops = _ops()
+    rng = np.random.default_rng(2)
+    s = synth_cloud(rng, 2000); q = s[::4].copy()
+    idx, _, _ = native.radius_neighbors(q, s, np.array([len(q)], np.int32), np.array([len(s)], np.int32), 0.1, 40)
+    x = rng.standard_normal((len(s), 128)).astype(np.float32)
+    ref = regtr_ref.max_pool(torch.from_numpy(x), torch.from_numpy(idx.astype(np.int64)))
+    assert torch.equal(ops.maxpool(to_dev(x), to_dev(idx)).cpu(), ref)
+    for C, lens in [(64, [700, 0, 1300]), (1024, [301, 450]), (32, [20000, 9]), (256, [1, 2])]:
+        n = sum(lens)
+        y = (rng.standard_normal((n, C)) * rng.uniform(0.1, 5, C) + rng.uniform(-3, 3, C)).astype(np.float32)
+        res = rng.standard_normal((n, C)).astype(np.float32)
+        seg = seg_of(lens)
+        st = ops.instnorm_stats(to_dev(y), seg, max(lens))
+        out = ops.instnorm_apply(to_dev(y), seg, max(lens), st, lrelu=True).cpu()
+        L = torch.tensor(lens)
+        ref = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(y), L), 0.1)
+        assert (out - ref).abs().max() < 2e-5
+        st2 = ops.instnorm_stats(to_dev(res), seg, max(lens))
+        out2 = ops.instnorm_apply(to_dev(y), seg, max(lens), st, residual=to_dev(res), res_stats=st2, lrelu=True).cpu()
+        ref2 = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(y), L) +
+                                              regtr_ref.instance_norm(torch.from_numpy(res), L), 0.1)
+        assert (out2 - ref2).abs().max() < 4e-5
+
+
+# ------------------------------------------------------------------------------------------------ transformer kernels
+def test_layernorm_posemb_vs_oracle():
+    from oracle import regtr_ref
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(751, 256, generator=g) * 3 + 1
+    gm, bt, add = torch.randn(256, generator=g), torch.randn(256, generator=g), torch.randn(751, 256, generator=g)
+    ref = torch.nn.functional.layer_norm(x, (256,), gm, bt)
+    out, plain = ops.layernorm(x.cuda(), gm.cuda(), bt.cuda(), add=add.cuda(), want_plain=True)
+    assert (plain.cpu() - ref).abs().max() < 1e-5 and (out.cpu() - (ref + add)).abs().max() < 1e-5
+    xyz = (torch.rand(613, 3, generator=g) - 0.5) * 8
+    pe = ops.posemb_sine(xyz.cuda(), 256, 1.0).cpu()
+    assert (pe - regtr_ref.pos_embed_sine(xyz, 256, 1.0)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900]])
+def test_mha_vs_oracle(lens):
+    """self- and cross-attention cores on packed ragged clouds vs the plain softmax(QK^T)V restatement."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(lens))
+    N, E, H = sum(lens), 256, 8
+    qkv = torch.randn(N, 3 * E, generator=g) * 1.5
+    seg = np.concatenate([[0], np.cumsum(lens)])
+    B = len(lens) // 2
+    for kv in (list(range(2 * B)), list(range(B, 2 * B)) + list(range(B))):
+        out = ops.mha(qkv.cuda()[:, :E], qkv.cuda()[:, E:2 * E], qkv.cuda()[:, 2 * E:], seg_of(lens),
+                      torch.tensor(kv, dtype=torch.int32).cuda(), max(lens), H).cpu()
+        for c in range(2 * B):
+            q = qkv[seg[c]:seg[c + 1], :E].view(-1, H, 32).transpose(0, 1) / math.sqrt(32)
+            k = qkv[seg[kv[c]]:seg[kv[c] + 1], E:2 * E].view(-1, H, 32).transpose(0, 1)
+            v = qkv[seg[kv[c]]:seg[kv[c] + 1], 2 * E:].view(-1, H, 32).transpose(0, 1)
+            ref = (torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()).transpose(0, 1).reshape(-1, E)
+            assert (out[seg[c]:seg[c + 1]].double() - ref).abs().max() < 2e-5
+
+
+def test_procrustes_vs_oracle():
+    from oracle import regtr_ref
+    from regtr_amd.se3 import compute_rigid_transform
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    B, L = 3, 6
+    lens = [412, 339, 100, 50, 77, 601]           # [src_0, src_1, src_2, tgt_0, tgt_1, tgt_2]
+    N = sum(lens)
+    kp = (torch.rand(N, 3, generator=g) - 0.5) * 4
+    corr = kp.unsqueeze(0) + torch.randn(L, N, 3, generator=g) * 0.3
+    logit = torch.randn(L, N, generator=g) * 2
+    pose = ops.weighted_procrustes(kp.cuda(), corr.cuda(), logit.cuda(), seg_of(lens), B).cpu()
+    seg = np.concatenate([[0], np.cumsum(lens)])
+    for b in range(B):
+        s, t = slice(seg[b], seg[b + 1]), slice(seg[B + b], seg[B + b + 1])
+        a = torch.cat([kp[s].expand(L, -1, -1), corr[:, t]], 1)
+        bb = torch.cat([corr[:, s], kp[t].expand(L, -1, -1)], 1)
+        w = torch.sigmoid(torch.cat([logit[:, s], logit[:, t]], 1))
+        ref = regtr_ref.compute_rigid_transform(a, bb, w)
+        assert (pose[:, b] - ref).abs().max() < 1e-4
+        R = pose[:, b, :, :3]
+        assert (R @ R.transpose(1, 2) - torch.eye(3)).abs().max() < 1e-5 and (torch.det(R) - 1).abs().max() < 1e-5
+    # generic drop-in of utils/se3_torch.py:compute_rigid_transform incl. a reflection-prone (planar) case
+    a = torch.rand(5, 200, 3, generator=g); a[..., 2] *= 1e-3
+    Rt = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    Rt = Rt * torch.det(Rt).sign()
+    b = a @ Rt.T + torch.tensor([0.3, -1.0, 2.0])
+    w = torch.rand(5, 200, generator=g)
+    T = compute_rigid_transform(a.cuda(), b.cuda(), w.cuda()).cpu()
+    assert (T - regtr_ref.compute_rigid_transform(a, b, w)).abs().max() < 1e-4
+    assert (T[:, :, :3] - Rt).abs().max() < 1e-3

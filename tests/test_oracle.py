@@ -1,0 +1,93 @@
+"""CPU: pins the oracle (oracle/) against the reference -- golden fixtures made by the real reference
+(oracle/make_golden.py) and, where oracle/_ref is present, the unmodified reference C++ itself."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native, regtr_ref
+from tests.util import canon_rows, gold, load_cfg, seeded_sd, synth_cloud
+
+
+@pytest.mark.parametrize('case', ['modelnet', '3dmatch_crop'])
+def test_grid_subsample_vs_reference_fixture(case):
+    g = gold(f'native_{case}')
+    pts, lens = g['pts'], g['lens']
+    # reference row order (libstdc++ unordered_map iteration): bit exact, row for row
+    op, ol = native.grid_subsample(pts, lens, float(g['dl']), ref_order=True)
+    assert np.array_equal(ol, g['sub_lens'])
+    assert np.array_equal(op.view(np.uint32), g['sub_pts'].view(np.uint32))
+    # canonical order: same multiset of barycentres per cloud, bit exact
+    cp, cl = native.grid_subsample(pts, lens, float(g['dl']))
+    assert np.array_equal(cl, ol)
+    o = 0
+    for n in cl:
+        a, b = cp[o:o + n], op[o:o + n]
+        assert np.array_equal(a[np.lexsort(a.T[::-1])].view(np.uint32), b[np.lexsort(b.T[::-1])].view(np.uint32))
+        o += n
+
+
+@pytest.mark.parametrize('case', ['modelnet', '3dmatch_crop'])
+def test_radius_vs_reference_fixture(case):
+    g = gold(f'native_{case}')
+    pts, lens, r = g['pts'], g['lens'], float(g['radius'])
+    ref = g['neighbors']                                   # untruncated (Nq, max_count), reference tie order
+    W = ref.shape[1]
+    idx, cnt, tie = native.radius_neighbors(pts, pts, lens, lens, r, W)
+    assert cnt.max() == W                                  # row width = max count (neighbors.cpp:290-293)
+    assert np.array_equal((ref != len(pts)).sum(1), cnt)
+    assert np.array_equal(canon_rows(ref, pts, pts, len(pts)), idx)
+    # pooled queries (subsampled points vs full cloud)
+    pool = g['pools']
+    idx2, cnt2, _ = native.radius_neighbors(g['sub_pts'], pts, g['sub_lens'], lens, r, pool.shape[1])
+    assert np.array_equal(canon_rows(pool, g['sub_pts'], pts, len(pts)), idx2)
+    # truncation at K: the first K canonical entries, tie rows flagged
+    K = max(2, W // 2)
+    idxk, cntk, tiek = native.radius_neighbors(pts, pts, lens, lens, r, K)
+    assert np.array_equal(idxk, idx[:, :K]) and np.array_equal(cntk, cnt)
+
+
+@pytest.mark.skipif(not native.have_ref(), reason='oracle/_ref not built (needs /root/reference)')
+def test_native_vs_unmodified_reference_cpp():
+    rng = np.random.default_rng(3)
+    clouds = [synth_cloud(rng, n, lattice=0.006) for n in (900, 1, 1500)]
+    pts = np.concatenate(clouds); lens = np.array([len(c) for c in clouds], np.int32)
+    for dl in (0.05, 0.11):
+        rp, rl = native.ref_subsample_batch(pts, lens, dl)
+        op, ol = native.grid_subsample(pts, lens, dl, ref_order=True)
+        assert np.array_equal(rl, ol) and np.array_equal(rp.view(np.uint32), op.view(np.uint32))
+    ref = native.ref_batch_query(pts, pts, lens, lens, 0.0625)
+    idx, cnt, _ = native.radius_neighbors(pts, pts, lens, lens, 0.0625, ref.shape[1])
+    assert np.array_equal(canon_rows(ref, pts, pts, len(pts)), idx)
+    # the reference's own brute-force variant (neighbors.cpp:125-208) breaks ties by index: equal without canonicalising
+    ordered = native.ref_batch_query(pts, pts, lens, lens, 0.0625, ordered=True)
+    assert np.array_equal(ordered, idx)
+
+
+@pytest.mark.parametrize('case,cfgn', [('modelnet_demo', 'modelnet'), ('3dmatch_crop', '3dmatch')])
+def test_float_restatement_vs_reference_golden(case, cfgn):
+    """oracle/regtr_ref.py driven in the REFERENCE's row order reproduces the reference module's outputs."""
+    if not native.have_ref():
+        pytest.skip('needs oracle/_ref for the reference row order')
+    g = gold(case)
+    cfg = load_cfg(cfgn)
+    sd = seeded_sd(cfg)
+    with torch.no_grad():
+        out = regtr_ref.regtr_forward(sd, cfg, [g['src']], [g['tgt']], use_ref_cpp=True)
+    assert np.array_equal(out['src_kp'][0].numpy(), g['src_kp'])
+    for k in ('src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap'):
+        assert np.abs(out[k][0].numpy() - g[k]).max() < 5e-5, k
+    assert np.abs(out['pose'].numpy() - g['pose']).max() < 5e-5
+    if 'src_feat_last' in g:
+        assert np.abs(out['src_feat'][0][-1].numpy() - g['src_feat_last']).max() < 5e-5
+
+
+def test_reference_order_pyramid_matches_golden():
+    """Level points of the kitchen pair in the reference's order are bit exact at every level."""
+    g = gold('3dmatch_kitchen')
+    pts = np.concatenate([g['src'], g['tgt']]); lens = np.array([len(g['src']), len(g['tgt'])], np.int32)
+    dl = 0.05
+    for l in (1, 2, 3):
+        pts, lens = native.grid_subsample(pts, lens, dl, ref_order=True)
+        assert np.array_equal(pts.view(np.uint32), g[f'points_{l}'].view(np.uint32))
+        assert np.array_equal(lens, g[f'lens_{l}'])
+        dl *= 2
