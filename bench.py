@@ -103,19 +103,24 @@ def measure_kpconv_roofline(model, batch, reps=5):
     L = _lib.lib()
     real_kpconv = ops.kpconv
 
-    def timed_kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent):
+    def timed_kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None,
+                     slope=0.1):
         nq, H = nbr.shape
         ns, Cin = x.shape
         KP = kernel_points.shape[0]
+        n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
         flag = torch.empty(ns, dtype=torch.float32, device=x.device)
-        _lib.check(L.regtr_rowsum_positive(_lib.ptr(x), ns, Cin, _lib.ptr(flag), _lib.stream()), 'rowsum')
+        _lib.check(L.regtr_rowsum_positive(_lib.ptr(x), ns, Cin, _lib.ptr(x_stats),
+                                           _lib.ptr(s_seg_off) if x_stats is not None else None, n_seg, slope,
+                                           _lib.ptr(flag), _lib.stream()), 'rowsum')
         wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=x.device)
         num = torch.empty(nq, dtype=torch.float32, device=x.device)
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
         _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_xyz), nq, _lib.ptr(s_xyz), ns, _lib.ptr(nbr), H, _lib.ptr(x), Cin,
-                                         _lib.ptr(flag), _lib.ptr(kernel_points), KP, float(extent), _lib.ptr(wf),
-                                         _lib.ptr(num), _lib.stream()), 'gather')
+                                         _lib.ptr(flag), _lib.ptr(kernel_points), KP, float(extent), _lib.ptr(x_stats),
+                                         _lib.ptr(q_seg_off) if x_stats is not None else None, n_seg, slope,
+                                         _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
         e1.record()
         out = ops.gemm(wf, w_flat, row_div=num)
         e2.record()
@@ -146,12 +151,12 @@ def measure_kpconv_roofline(model, batch, reps=5):
     }
 
 
-def cpu_baseline(cfg, pairs, max_seconds=30.0):
+def cpu_baseline(cfg, pairs, max_seconds=20.0):
     """The CPU oracle port (oracle/regtr_ref.py; preprocessing through the unmodified reference C++ when oracle/_ref is
     present) on this box's host cores, same workload, bounded sample."""
     from oracle import native, regtr_ref, seeded_weights
     from regtr_amd.kernel_points import K015_CENTER
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 16))   # more threads than this slow the small torch CPU ops down
     sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
     use_ref = native.have_ref()
     times, stages = [], []

@@ -71,14 +71,18 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
 
 /* ---- KPConv encoder --------------------------------------------------------------------------------------- */
 
-/* flag[j] = (sum_c x[j,c] > 0) ? 1 : 0   -- the per-support term of the reference's normaliser (kpconv_blocks.py:409-410) */
-int regtr_rowsum_positive(const float* x, int n, int C, float* flag, void* stream);
+/* flag[j] = (sum_c x'[j,c] > 0) ? 1 : 0   -- the per-support term of the reference's normaliser (kpconv_blocks.py:409-410).
+ * x' = x, or LeakyReLU_slope(InstanceNorm(x)) when stats [n_seg,C,2] + seg_off [n_seg+1] are given (fused UnaryBlock tail). */
+int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
+                          float* flag, void* stream);
 
 /* wf [nq, KP*Cin] (kernel point major, channel minor), num [nq] = max(1, #positive neighbours).  nbr [nq,H] int32,
- * x [ns,Cin], flag [ns], kernel_points [KP,3], KP <= 16. */
+ * x [ns,Cin], flag [ns], kernel_points [KP,3], KP <= 16.  x_stats [n_seg,Cin,2] + q_seg_off [n_seg+1] (optional): the
+ * gathered features are LeakyReLU_slope(InstanceNorm(x)) computed on the fly (cloud of a neighbour = cloud of its query). */
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                        int Cin, const float* flag, const float* kernel_points, int KP, float extent, float* wf,
-                        float* num, void* stream);
+                        int Cin, const float* flag, const float* kernel_points, int KP, float extent,
+                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
+                        void* stream);
 
 int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream);
 
@@ -91,9 +95,14 @@ int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int m
 
 /* ---- dense ------------------------------------------------------------------------------------------------- */
 
-/* C[M,N] = act(A[M,K] B[K,N] / row_div[m] + bias[n]) + residual[m,n] ; float32 MFMA ; act: 0 none, 1 ReLU */
+/* C[M,N] = act(A'[M,K] B[K,N] / row_div[m] + bias[n]) + residual[m,n] ; float32 MFMA ; act: 0 none, 1 ReLU.
+ * A' = A, or LeakyReLU_slope(InstanceNorm(A)) when a_stats [n_seg,K,2] + a_seg_off [n_seg+1] are given.
+ * ws: regtr_gemm_f32_ws_bytes(M,N,K) bytes of scratch for the split-K path (0 for most shapes; ws may then be NULL). */
+size_t regtr_gemm_f32_ws_bytes(int M, int N, int K);
 int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                   const float* bias, const float* row_div, const float* residual, int ldr, int act, void* stream);
+                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
+                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
+                   void* stream);
 
 int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
                     float* y, float* y_plain, void* stream);

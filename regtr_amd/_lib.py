@@ -24,13 +24,14 @@ SIGNATURES = {
     'regtr_cellgrid_ws_bytes': (_Z, [_I, _I]),
     'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
     'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
-    'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P]),
-    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
+    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),
     'regtr_instnorm_apply': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P]),
-    'regtr_gemm_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P]),
+    'regtr_gemm_f32_ws_bytes': (_Z, [_I, _I, _I]),
+    'regtr_gemm_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P]),
     'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -61,24 +61,34 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
     for (int r = 0; r < 16; r++) o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
+    // K / V tiles: 32 rows x 32 floats each; a row is one 128-B line, 8 lanes per row.  The next tile's global loads are
+    // issued before the MFMAs of the current one (register staging), so HBM/L2 latency hides under compute.
+    float4 kreg[4], vreg[4];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+            const int krow = kt + it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[it] = kreg[it];
+            if (krow < nk) {
+                kreg[it] = *(const float4*)(g.k + (size_t)(k_begin + krow) * g.ldk + hoff + c4);
+                vreg[it] = *(const float4*)(g.v + (size_t)(k_begin + krow) * g.ldv + hoff + c4);
+            }
+        }
+    };
+    fetch(0);
     for (int kt = 0; kt < nk; kt += TK) {
-        // stage the K and V tiles: 32 rows x 32 floats each; a row is one 128-B line, 8 lanes per row
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-            const int krow = kt + row;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-            if (krow < nk) {
-                kv = *(const float4*)(g.k + (size_t)(k_begin + krow) * g.ldk + hoff + c4);
-                vv = *(const float4*)(g.v + (size_t)(k_begin + krow) * g.ldv + hoff + c4);
-            }
             float* kd = &Ks[row * LDS_STRIDE + c4];
-            kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+            kd[0] = kreg[it].x; kd[1] = kreg[it].y; kd[2] = kreg[it].z; kd[3] = kreg[it].w;
             float* vd = &Vs[row * LDS_STRIDE + c4];
-            vd[0] = vv.x; vd[1] = vv.y; vd[2] = vv.z; vd[3] = vv.w;
+            vd[0] = vreg[it].x; vd[1] = vreg[it].y; vd[2] = vreg[it].z; vd[3] = vreg[it].w;
         }
         __syncthreads();
+        if (kt + TK < nk) fetch(kt + TK);
 
         // S^T tile: rows = keys, cols = queries
         floatx16 sc;

@@ -6,82 +6,127 @@
 // (regtr.py:145), the attention in/out projections and FFN (transformers.py:197-238) and the correspondence head
 // (regtr.py:432-436).  Weights are stored pre-transposed as B[K,N] row-major so B-fragment loads are contiguous.
 //
-// Tile: 64x64 per 256-thread workgroup (4 waves, 2x2, one 32x32 accumulator each), BK = 16, LDS double-buffered
-// with the next tile's global loads issued before the MFMAs of the current one.  Fused epilogue:
-//   v = acc ; v /= row_div[m] ; v += bias[n] ; act ; v += residual[m,n]
+// Tiles: 256-thread workgroups of 4 waves, one 32x32 accumulator per wave, arranged 2x2 (64x64 tile) or, for thin
+// outputs (N <= 32: the level-0 KPConv contraction and unary1), 4x1 (128x32 tile) so no MFMA work is spent on
+// padding columns.  BK = 16, LDS double-buffered with the next tile's global loads issued before the current MFMAs.
+// Small-M / deep-K problems (the 750-token transformer and level-3 KPConv contractions: a few hundred tiles with a
+// serial chain of K/2 MFMAs each) are split along K across workgroups; partial tiles go to a workspace and a second
+// kernel reduces them in fixed order (deterministic) and applies the epilogue.
+// Fused epilogue:   v = acc ; v /= row_div[m] ; v += bias[n] ; act ; v += residual[m,n]
+// Optional A-operand transform (per-cloud InstanceNorm + LeakyReLU folded into the load, kpconv_blocks.py:727-730):
+//   a[m,k] <- lrelu((a[m,k] - mean[cloud(m),k]) * rstd[cloud(m),k])
 #include "common.h"
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16;
+constexpr int BK = 16;
 constexpr int LDA_S = BK + 1;   // odd stride: A-fragment column reads hit 32 distinct banks
-constexpr int LDB_S = BN + 1;
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias; const float* row_div; const float* residual;
-    int M, N, K, lda, ldb, ldc, ldr, act;
+    const float2* a_stats; const int* a_seg_off;   // optional fused InstanceNorm+LeakyReLU on A
+    float* partial;                                  // split-K workspace [S][M][N] (raw accumulators)
+    int M, N, K, lda, ldb, ldc, ldr, act, n_seg, k_chunk;
+    float a_slope;
 };
 
-template <bool ALIGNED>
-__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, float (&ra)[4], float (&rb)[4])
+template <bool ALIGNED, int BM, int BN>
+__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, int k_end,
+                                           float (&ra)[BM / 64][4], float (&rb)[4], const int* row_seg)
 {
     const int t = threadIdx.x;
-    {   // A: 64 rows x 16 k  -> thread (row = t/4, k4 = (t%4)*4)
-        const int row = m0 + (t >> 2), k = k0 + (t & 3) * 4;
+#pragma unroll
+    for (int i = 0; i < BM / 64; i++) {   // A: BM rows x 16 k -> (row = idx/4, k4 = (idx%4)*4)
+        const int idx = t + i * 256;
+        const int row = m0 + (idx >> 2), k = k0 + (idx & 3) * 4;
         if (ALIGNED) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < g.M && k < g.K) v = *(const float4*)(g.A + (size_t)row * g.lda + k);
-            ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+            if (row < g.M && k < k_end) v = *(const float4*)(g.A + (size_t)row * g.lda + k);
+            ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) ra[j] = (row < g.M && k + j < g.K) ? g.A[(size_t)row * g.lda + k + j] : 0.f;
+            for (int j = 0; j < 4; j++) ra[i][j] = (row < g.M && k + j < k_end) ? g.A[(size_t)row * g.lda + k + j] : 0.f;
+        }
+        if (g.a_stats && row < g.M) {
+            const float2* st = g.a_stats + (size_t)row_seg[i] * g.K + k;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k + j < k_end) {
+                    const float2 s = st[j];
+                    const float v = (ra[i][j] - s.x) * s.y;
+                    ra[i][j] = v > 0.f ? v : v * g.a_slope;
+                }
         }
     }
-    {   // B: 16 k x 64 n -> thread (k = t/16, n4 = (t%16)*4)
-        const int k = k0 + (t >> 4), n = n0 + (t & 15) * 4;
-        if (ALIGNED) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < g.K && n < g.N) v = *(const float4*)(g.B + (size_t)k * g.ldb + n);
-            rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
-        } else {
+    {   // B: 16 k x BN n -> (k = t / (BN/4), n4 = (t % (BN/4)) * 4)
+        constexpr int NV = BN / 4;
+        const int k = k0 + t / NV, n = n0 + (t % NV) * 4;
+        rb[0] = rb[1] = rb[2] = rb[3] = 0.f;
+        if (t < BK * NV) {
+            if (ALIGNED) {
+                if (k < k_end && n < g.N) {
+                    const float4 v = *(const float4*)(g.B + (size_t)k * g.ldb + n);
+                    rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) rb[j] = (k < g.K && n + j < g.N) ? g.B[(size_t)k * g.ldb + n + j] : 0.f;
+                for (int j = 0; j < 4; j++) rb[j] = (k < k_end && n + j < g.N) ? g.B[(size_t)k * g.ldb + n + j] : 0.f;
+            }
         }
     }
 }
 
-template <bool ALIGNED>
+// WMW x WNW waves, each a 32x32 accumulator
+template <bool ALIGNED, int WMW, int WNW>
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 {
+    constexpr int BM = 32 * WMW, BN = 32 * WNW, LDB_S = BN + 1;
     __shared__ float As[2][BM * LDA_S];
     __shared__ float Bs[2][BK * LDB_S];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int l31 = lane & 31, hi = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int nk = (g.K + BK - 1) / BK;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    int row_seg[BM / 64];
+#pragma unroll
+    for (int i = 0; i < BM / 64; i++) {
+        row_seg[i] = 0;
+        const int row = m0 + ((t + i * 256) >> 2);
+        if (g.a_stats && row < g.M) row_seg[i] = rg_find_segment(g.a_seg_off, g.n_seg, row);
+    }
 
     floatx16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    float ra[4], rb[4];
-    load_tiles<ALIGNED>(g, m0, n0, 0, ra, rb);
+    float ra[BM / 64][4], rb[4];
+    load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra, rb, row_seg);
     auto stage = [&](int buf) {
-        float* a = &As[buf][(t >> 2) * LDA_S + (t & 3) * 4];
-        a[0] = ra[0]; a[1] = ra[1]; a[2] = ra[2]; a[3] = ra[3];
-        float* b = &Bs[buf][(t >> 4) * LDB_S + (t & 15) * 4];
-        b[0] = rb[0]; b[1] = rb[1]; b[2] = rb[2]; b[3] = rb[3];
+#pragma unroll
+        for (int i = 0; i < BM / 64; i++) {
+            const int idx = t + i * 256;
+            float* a = &As[buf][(idx >> 2) * LDA_S + (idx & 3) * 4];
+            a[0] = ra[i][0]; a[1] = ra[i][1]; a[2] = ra[i][2]; a[3] = ra[i][3];
+        }
+        constexpr int NV = BN / 4;
+        if (t < BK * NV) {
+            float* b = &Bs[buf][(t / NV) * LDB_S + (t % NV) * 4];
+            b[0] = rb[0]; b[1] = rb[1]; b[2] = rb[2]; b[3] = rb[3];
+        }
     };
     stage(0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; kt++) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles<ALIGNED>(g, m0, n0, (kt + 1) * BK, ra, rb);
+        if (kt + 1 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 1) * BK, k_end, ra, rb, row_seg);
         const float* a = &As[cur][(wm * 32 + l31) * LDA_S + hi];
         const float* b = &Bs[cur][hi * LDB_S + wn * 32 + l31];
 #pragma unroll
@@ -93,6 +138,15 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 
     const int col = n0 + wn * 32 + l31;
     if (col >= g.N) return;
+    if (g.partial) {   // split-K: raw accumulators, epilogue happens in k_splitk_reduce
+        float* P = g.partial + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (row < g.M) P[(size_t)row * g.N + col] = acc[r];
+        }
+        return;
+    }
     const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -107,22 +161,75 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     }
 }
 
+__global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int S)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)g.M * g.N) return;
+    const int row = (int)(e / g.N), col = (int)(e % g.N);
+    float v = 0.f;
+    for (int s = 0; s < S; s++) v += g.partial[(size_t)s * g.M * g.N + e];   // fixed order: deterministic
+    if (g.row_div) v = v / g.row_div[row];
+    if (g.bias) v += g.bias[col];
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
+}
+
+// number of K splits for a problem (host policy; 1 = no split)
+int choose_splits(int M, int N, int K, int bm, int bn)
+{
+    const long long tiles = (long long)rg_cdiv(M, bm) * rg_cdiv(N, bn);
+    if (tiles >= 384 || K < 512) return 1;
+    int s = (int)((768 + tiles - 1) / tiles);
+    const int max_by_k = K / 128;          // keep >= 128 of K per split
+    if (s > max_by_k) s = max_by_k;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
 }  // namespace
 
 extern "C" {
 
+size_t regtr_gemm_f32_ws_bytes(int M, int N, int K)
+{
+    const int bm = N <= 32 ? 128 : 64, bn = N <= 32 ? 32 : 64;
+    const int s = choose_splits(M, N, K, bm, bn);
+    return s > 1 ? (size_t)s * M * N * sizeof(float) : 0;
+}
+
 // act: 0 none, 1 ReLU.  bias [N], row_div [M], residual [M, ldr] are optional (NULL).
+// a_stats [n_seg, K, 2] + a_seg_off [n_seg + 1] (optional): fold lrelu(InstanceNorm(A)) into the A load.
+// ws: regtr_gemm_f32_ws_bytes(M, N, K) bytes (may be NULL when that is 0).
 int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
-                   const float* bias, const float* row_div, const float* residual, int ldr, int act, void* stream)
+                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
+                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
+                   void* stream)
 {
     if (!A || !B || !C || M < 0 || N < 1 || K < 1 || lda < K || ldb < N || ldc < N) return RG_ERR_ARG;
+    if (a_stats && (!a_seg_off || n_seg < 1)) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
-    GemmArgs g{A, B, C, bias, row_div, residual, M, N, K, lda, ldb, ldc, ldr, act};
+    const bool thin = N <= 32;
+    const int bm = thin ? 128 : 64, bn = thin ? 32 : 64;
+    const int S = choose_splits(M, N, K, bm, bn);
+    if (S > 1 && (!ws || ws_bytes < (size_t)S * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
+    int k_chunk = K;
+    if (S > 1) k_chunk = rg_cdiv(rg_cdiv(K, S), BK) * BK;
+    const int S_eff = rg_cdiv(K, k_chunk);
+    GemmArgs g{A, B, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off, S_eff > 1 ? (float*)ws : nullptr,
+               M, N, K, lda, ldb, ldc, ldr, act, n_seg, k_chunk, a_slope};
     const bool aligned = (K % 4 == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
-                         (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
-    dim3 grid(rg_cdiv(M, BM), rg_cdiv(N, BN));
-    if (aligned) k_gemm_f32<true><<<grid, 256, 0, (hipStream_t)stream>>>(g);
-    else k_gemm_f32<false><<<grid, 256, 0, (hipStream_t)stream>>>(g);
+                         (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (k_chunk % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(rg_cdiv(M, bm), rg_cdiv(N, bn), S_eff);
+    if (thin) {
+        if (aligned) k_gemm_f32<true, 4, 1><<<grid, 256, 0, st>>>(g);
+        else k_gemm_f32<false, 4, 1><<<grid, 256, 0, st>>>(g);
+    } else {
+        if (aligned) k_gemm_f32<true, 2, 2><<<grid, 256, 0, st>>>(g);
+        else k_gemm_f32<false, 2, 2><<<grid, 256, 0, st>>>(g);
+    }
+    if (S_eff > 1) k_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, S_eff);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -21,14 +21,22 @@ namespace {
 constexpr int KP_PAD = 16;   // kernel points padded to 16 per neighbour (15 used)
 constexpr int GATHER_WAVES = 4;
 
-// flag[j] = (sum_c x[j, c] > 0) for every support row; the shadow row (index ns) is 0 by construction.
-__global__ void __launch_bounds__(256) k_rowsum_positive(const float* __restrict__ x, int n, int C, float* __restrict__ flag)
+// flag[j] = (sum_c x'[j, c] > 0) for every support row, x' = x or lrelu(InstanceNorm(x)) when stats are given;
+// the shadow row (index ns) is 0 by construction.
+__global__ void __launch_bounds__(256) k_rowsum_positive(const float* __restrict__ x, int n, int C, const float2* __restrict__ stats,
+                                                         const int* __restrict__ seg_off, int n_seg, float slope,
+                                                         float* __restrict__ flag)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n) return;
     const int lane = rg_lane();
+    const float2* st = stats ? stats + (size_t)rg_find_segment(seg_off, n_seg, row) * C : nullptr;
     float s = 0.f;
-    for (int c = lane; c < C; c += RG_WAVE) s += x[(size_t)row * C + c];
+    for (int c = lane; c < C; c += RG_WAVE) {
+        float v = x[(size_t)row * C + c];
+        if (st) { v = (v - st[c].x) * st[c].y; v = v > 0.f ? v : v * slope; }
+        s += v;
+    }
     s = rg_wave_sum(s);
     if (lane == 0) flag[row] = s > 0.f ? 1.f : 0.f;
 }
@@ -36,8 +44,9 @@ __global__ void __launch_bounds__(256) k_rowsum_positive(const float* __restrict
 struct GatherArgs {
     const float* q_xyz; const float* s_xyz; const int* nbr; const float* x; const float* flag; const float* kp;
     float* wf; float* num;
-    int nq, ns, H, Cin, KP;
-    float extent;
+    const float2* x_stats; const int* q_seg_off;     // optional fused lrelu(InstanceNorm(x)) on the gathered features
+    int nq, ns, H, Cin, KP, n_seg;
+    float extent, slope;
 };
 
 // LQ = lanes per query (16, 32 or 64); a wave handles 64 / LQ queries at a time.
@@ -48,12 +57,13 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     extern __shared__ __align__(16) float smem[];
     const int wave = threadIdx.x >> 6, lane = rg_lane();
     const int H = g.H;
-    // per-wave LDS: w[QW][H][16] | rel[QW][H][3] | nidx[QW][H] | flag[QW][H]
-    const int per_wave = (QW * H * (KP_PAD + 5) + 3) & ~3;   // keep every wave's tile 16-B aligned
+    // per-wave LDS: w[QW][H][16] | rel[QW][H][3] | nidx[QW][H] | flag[QW][H] | x[QW][H] (Cin == 1 only)
+    const int per_wave = (QW * H * (KP_PAD + 6) + 3) & ~3;   // keep every wave's tile 16-B aligned
     float* w_s = smem + (size_t)wave * per_wave;
     float* rel_s = w_s + QW * H * KP_PAD;
     int* idx_s = (int*)(rel_s + QW * H * 3);
     float* flg_s = (float*)(idx_s + QW * H);
+    float* xs_s = flg_s + QW * H;
 
     const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
     if (q0 >= g.nq) return;   // wave-uniform
@@ -62,17 +72,18 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     for (int e = lane; e < QW * H; e += RG_WAVE) {
         const int qi = e / H, h = e - qi * H, q = q0 + qi;
         int idx = g.ns;
-        float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f;
+        float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f, x1 = 0.f;
         if (q < g.nq) {
             idx = g.nbr[(size_t)q * H + h];
             float sx = 1e6f, sy = 1e6f, sz = 1e6f;            // shadow support point  (kpconv_blocks.py:309)
             if (idx < g.ns) {
                 sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
                 f = g.flag[idx];
+                if (g.Cin == 1) x1 = g.x[idx];
             }
             rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
         }
-        idx_s[e] = idx; flg_s[e] = f;
+        idx_s[e] = idx; flg_s[e] = f; xs_s[e] = x1;
         rel_s[3 * e] = rx; rel_s[3 * e + 1] = ry; rel_s[3 * e + 2] = rz;
     }
     __builtin_amdgcn_wave_barrier();
@@ -102,27 +113,45 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     const float* wq = w_s + (size_t)qi * H * KP_PAD;
     const int* iq = idx_s + qi * H;
     const int Cin = g.Cin;
-    for (int c = cl; c < Cin; c += LQ) {
-        float acc[KP_PAD];
-#pragma unroll
-        for (int k = 0; k < KP_PAD; k++) acc[k] = 0.f;
-        for (int h = 0; h < H; h++) {
-            const int idx = iq[h];
-            const float xv = idx < g.ns ? g.x[(size_t)idx * Cin + c] : 0.f;       // zero shadow feature (:388)
-            const float4* w4 = (const float4*)(wq + h * KP_PAD);
-#pragma unroll
-            for (int j = 0; j < KP_PAD / 4; j++) {
-                const float4 wv = w4[j];
-                acc[4 * j + 0] = fmaf(wv.x, xv, acc[4 * j + 0]);
-                acc[4 * j + 1] = fmaf(wv.y, xv, acc[4 * j + 1]);
-                acc[4 * j + 2] = fmaf(wv.z, xv, acc[4 * j + 2]);
-                acc[4 * j + 3] = fmaf(wv.w, xv, acc[4 * j + 3]);
-            }
+    if (Cin == 1) {
+        // single input channel (first encoder block): lanes = kernel points, features already staged in LDS
+        if (LQ == 16 && cl < g.KP) {
+            const float* xq = xs_s + qi * H;
+            float acc = 0.f;
+            for (int h = 0; h < H; h++) acc = fmaf(wq[h * KP_PAD + cl], xq[h], acc);
+            g.wf[(size_t)q * g.KP + cl] = acc;
         }
-        float* o = g.wf + (size_t)q * g.KP * Cin + c;
+    } else {
+        const float2* st = nullptr;
+        if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
+        for (int c = cl; c < Cin; c += LQ) {
+            float acc[KP_PAD];
 #pragma unroll
-        for (int k = 0; k < KP_PAD; k++)
-            if (k < g.KP) o[(size_t)k * Cin] = acc[k];
+            for (int k = 0; k < KP_PAD; k++) acc[k] = 0.f;
+            float mu = 0.f, rs = 1.f;
+            if (st) { mu = st[c].x; rs = st[c].y; }
+            for (int h = 0; h < H; h++) {
+                const int idx = iq[h];
+                float xv = 0.f;                                                    // zero shadow feature (:388)
+                if (idx < g.ns) {
+                    xv = g.x[(size_t)idx * Cin + c];
+                    if (st) { xv = (xv - mu) * rs; xv = xv > 0.f ? xv : xv * g.slope; }
+                }
+                const float4* w4 = (const float4*)(wq + h * KP_PAD);
+#pragma unroll
+                for (int j = 0; j < KP_PAD / 4; j++) {
+                    const float4 wv = w4[j];
+                    acc[4 * j + 0] = fmaf(wv.x, xv, acc[4 * j + 0]);
+                    acc[4 * j + 1] = fmaf(wv.y, xv, acc[4 * j + 1]);
+                    acc[4 * j + 2] = fmaf(wv.z, xv, acc[4 * j + 2]);
+                    acc[4 * j + 3] = fmaf(wv.w, xv, acc[4 * j + 3]);
+                }
+            }
+            float* o = g.wf + (size_t)q * g.KP * Cin + c;
+#pragma unroll
+            for (int k = 0; k < KP_PAD; k++)
+                if (k < g.KP) o[(size_t)k * Cin] = acc[k];
+        }
     }
     if (cl == 0) {
         float cnt = 0.f;
@@ -156,29 +185,33 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
 
 extern "C" {
 
-int regtr_rowsum_positive(const float* x, int n, int C, float* flag, void* stream)
+int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
+                          float* flag, void* stream)
 {
-    if (!x || !flag || n < 0 || C < 1) return RG_ERR_ARG;
+    if (!x || !flag || n < 0 || C < 1 || (stats && (!seg_off || n_seg < 1))) return RG_ERR_ARG;
     if (n == 0) return RG_OK;
-    k_rowsum_positive<<<rg_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(x, n, C, flag);
+    k_rowsum_positive<<<rg_cdiv(n, 4), 256, 0, (hipStream_t)stream>>>(x, n, C, (const float2*)stats, seg_off, n_seg, slope,
+                                                                       flag);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
 
 // wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                        int Cin, const float* flag, const float* kernel_points, int KP, float extent, float* wf,
-                        float* num, void* stream)
+                        int Cin, const float* flag, const float* kernel_points, int KP, float extent,
+                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
+                        void* stream)
 {
     if (!q_xyz || !s_xyz || !nbr || !x || !flag || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
-        Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f))
+        Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f) || (x_stats && (!q_seg_off || n_seg < 1)))
         return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
-    GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, nq, ns, H, Cin, KP, extent};
+    GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
+                 nq, ns, H, Cin, KP, n_seg, extent, slope};
     hipStream_t st = (hipStream_t)stream;
     const int LQ = Cin <= 16 ? 16 : (Cin <= 32 ? 32 : 64);
     const int QW = RG_WAVE / LQ;
-    const size_t lds = (size_t)GATHER_WAVES * ((QW * H * (KP_PAD + 5) + 3) & ~3) * sizeof(float);
+    const size_t lds = (size_t)GATHER_WAVES * ((QW * H * (KP_PAD + 6) + 3) & ~3) * sizeof(float);
     if (lds > 160 * 1024) return RG_ERR_ARG;
     const int grid = rg_cdiv(nq, GATHER_WAVES * QW);
     if (LQ == 16) k_kpconv_gather<16><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);

@@ -9,9 +9,13 @@
 
 namespace {
 
-constexpr int IN_ROWS = 256;   // rows of one cloud handled by one workgroup
+constexpr int IN_ROWS = 128;   // rows of one cloud handled by one workgroup
 
-// partial[(cloud * nchunk + chunk) * C + c] = (sum, sumsq) over the chunk's rows
+// Thread mapping shared by the InstanceNorm kernels: C4 = C/4 float4 columns (a power of two <= 256); thread
+// (tx = t % C4, ty = t / C4) owns column group tx for rows ty, ty + TR, ... so that every row is one contiguous read and
+// the per-channel statistics a thread needs stay in registers for the whole tile.
+
+// partial[(cloud * nchunk + chunk) * C + c] = (sum, sumsq) over the chunk's rows, accumulated in float64
 __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
                                                           int nchunk, double2* __restrict__ partial)
 {
@@ -19,54 +23,63 @@ __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restric
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
     if (r0 >= r1) return;
-    const int C4 = C >> 2;
-    const int TC = C4 < 256 ? C4 : 256, TR = 256 / TC;
-    const int tx = threadIdx.x % TC, ty = threadIdx.x / TC;
-    for (int c4 = tx; c4 < C4; c4 += TC) {
-        double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
-        if (ty < TR)
-            for (int r = r0 + ty; r < r1; r += TR) {
-                const float4 v = *(const float4*)(x + (size_t)r * C + 4 * c4);
-                s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-                ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
-            }
-        __syncthreads();
+    const int C4 = C >> 2, TR = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float* base = x + 4 * tx;
+    for (int r = r0 + ty; r < r1; r += 4 * TR) {
+        float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) { sh[threadIdx.x * 8 + j] = s[j]; sh[threadIdx.x * 8 + 4 + j] = ss[j]; }
-        __syncthreads();
-        if (ty == 0) {
-            for (int y = 1; y < TR; y++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) { s[j] += sh[(y * TC + tx) * 8 + j]; ss[j] += sh[(y * TC + tx) * 8 + 4 + j]; }
-            double2* o = partial + ((size_t)b * nchunk + chunk) * C + 4 * c4;
-#pragma unroll
-            for (int j = 0; j < 4; j++) o[j] = make_double2(s[j], ss[j]);
+        for (int u = 0; u < 4; u++) {
+            const int rr = r + u * TR;
+            v[u] = rr < r1 ? *(const float4*)(base + (size_t)rr * C) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
+            ss[0] += (double)v[u].x * v[u].x; ss[1] += (double)v[u].y * v[u].y;
+            ss[2] += (double)v[u].z * v[u].z; ss[3] += (double)v[u].w * v[u].w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { sh[threadIdx.x * 8 + j] = s[j]; sh[threadIdx.x * 8 + 4 + j] = ss[j]; }
+    __syncthreads();
+    if (ty == 0) {
+        for (int y = 1; y < TR; y++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) { s[j] += sh[(y * C4 + tx) * 8 + j]; ss[j] += sh[(y * C4 + tx) * 8 + 4 + j]; }
+        double2* o = partial + ((size_t)b * nchunk + chunk) * C + 4 * tx;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[j] = make_double2(s[j], ss[j]);
     }
 }
 
-// stats[(cloud * C + c)] = (mean, 1/sqrt(var + eps))
+// stats[(cloud * C + c)] = (mean, 1/sqrt(var + eps)); one wave per (cloud, channel) sums the chunks in a fixed tree
 __global__ void __launch_bounds__(256) k_instnorm_finalize(const double2* __restrict__ partial, const int* __restrict__ seg_off,
                                                            int C, int nchunk, float eps, float2* __restrict__ stats)
 {
-    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
+    const int lane = rg_lane();
     const int n = seg_off[b + 1] - seg_off[b];
     const int used = (n + IN_ROWS - 1) / IN_ROWS;
     double s = 0, ss = 0;
-    for (int k = 0; k < used; k++) {
+    for (int k = lane; k < used; k += RG_WAVE) {
         const double2 p = partial[((size_t)b * nchunk + k) * C + c];
         s += p.x; ss += p.y;
     }
-    float mean = 0.f, rstd = 0.f;
-    if (n > 0) {
-        const double m = s / n;
-        double var = ss / n - m * m;
-        if (var < 0) var = 0;
-        mean = (float)m;
-        rstd = (float)(1.0 / sqrt(var + (double)eps));
+    s = rg_wave_sum(s); ss = rg_wave_sum(ss);
+    if (lane == 0) {
+        float mean = 0.f, rstd = 0.f;
+        if (n > 0) {
+            const double m = s / n;
+            double var = ss / n - m * m;
+            if (var < 0) var = 0;
+            mean = (float)m;
+            rstd = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        stats[(size_t)b * C + c] = make_float2(mean, rstd);
     }
-    stats[(size_t)b * C + c] = make_float2(mean, rstd);
 }
 
 // y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
@@ -78,30 +91,42 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
     if (r0 >= r1) return;
-    const int C4 = C >> 2;
-    const int total = (r1 - r0) * C4;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int r = r0 + e / C4, c = (e % C4) * 4;
-        float4 v = *(const float4*)(x + (size_t)r * C + c);
-        float o[4] = {v.x, v.y, v.z, v.w};
-        if (stats) {
+    const int C4 = C >> 2, TR = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, rmu[4] = {0.f, 0.f, 0.f, 0.f}, rrs[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-            for (int j = 0; j < 4; j++) { const float2 st = stats[(size_t)b * C + c + j]; o[j] = (o[j] - st.x) * st.y; }
-        }
-        if (res) {
-            const float4 rv = *(const float4*)(res + (size_t)r * C + c);
-            float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+    for (int j = 0; j < 4; j++) {
+        if (stats) { const float2 st = stats[(size_t)b * C + 4 * tx + j]; mu[j] = st.x; rs[j] = st.y; }
+        if (res_stats) { const float2 st = res_stats[(size_t)b * C + 4 * tx + j]; rmu[j] = st.x; rrs[j] = st.y; }
+    }
+    for (int r = r0 + ty; r < r1; r += 4 * TR) {
+        float4 v[4], rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (res_stats) { const float2 st = res_stats[(size_t)b * C + c + j]; rr[j] = (rr[j] - st.x) * st.y; }
-                o[j] += rr[j];
+        for (int u = 0; u < 4; u++) {
+            const int rr = r + u * TR;
+            if (rr < r1) {
+                v[u] = *(const float4*)(x + (size_t)rr * C + 4 * tx);
+                if (res) rv[u] = *(const float4*)(res + (size_t)rr * C + 4 * tx);
             }
         }
-        if (act == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+        for (int u = 0; u < 4; u++) {
+            const int rr = r + u * TR;
+            if (rr >= r1) continue;
+            float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = (o[j] - mu[j]) * rs[j];
+            if (res) {
+                const float q[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] += (q[j] - rmu[j]) * rrs[j];
+            }
+            if (act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
+            }
+            *(float4*)(y + (size_t)rr * C + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *(float4*)(y + (size_t)r * C + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -172,14 +197,13 @@ int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int m
                          void* ws, size_t ws_bytes, void* stream)
 {
     if (!x || !seg_off || !stats || n_clouds < 1 || C < 4 || C % 4 || max_len < 0) return RG_ERR_ARG;
-    if (C > 1024 && (C / 4) % 256) return RG_ERR_ARG;
-    if (C / 4 < 256 && 256 % (C / 4)) return RG_ERR_ARG;
+    if (C > 1024 || 256 % (C / 4)) return RG_ERR_ARG;      // C/4 float4 columns must be a power of two <= 256
     if (ws_bytes < regtr_instnorm_ws_bytes(n_clouds, max_len, C)) return RG_ERR_WORKSPACE;
     if (max_len == 0) return RG_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = rg_cdiv(max_len, IN_ROWS);
     k_instnorm_partial<<<dim3(nchunk, n_clouds), 256, 0, st>>>(x, seg_off, C, nchunk, (double2*)ws);
-    k_instnorm_finalize<<<dim3(rg_cdiv(C, 256), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, eps,
+    k_instnorm_finalize<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, eps,
                                                                          (float2*)stats);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
@@ -191,6 +215,7 @@ int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int m
                          const float* residual, const float* res_stats, int act, float slope, float* y, void* stream)
 {
     if (!x || !seg_off || !y || n_clouds < 1 || C < 4 || C % 4 || max_len < 0) return RG_ERR_ARG;
+    if (C > 1024 || 256 % (C / 4)) return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
     k_instnorm_apply<<<dim3(rg_cdiv(max_len, IN_ROWS), n_clouds), 256, 0, (hipStream_t)stream>>>(
         x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y);

@@ -151,44 +151,66 @@ __global__ void k_init_bbox(int* __restrict__ bbox, int n_clouds)
     if (i < n_clouds * 6) bbox[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
 }
 
-// per-cloud min / max corner  (cloud.cpp:27-66)
+// per-cloud min / max corner  (cloud.cpp:27-66).  Each wave walks BBOX_ITEMS strided points per lane and keeps a running
+// box in registers while the cloud stays the same, so the global atomics are ~one set per wave per cloud.
+constexpr int BBOX_ITEMS = 8;
+
+__device__ __forceinline__ void bbox_flush(int cid, float (&mn)[3], float (&mx)[3], int* __restrict__ bbox)
+{
+    if (cid < 0) return;   // wave-uniform
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, RG_WAVE));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, RG_WAVE));
+        }
+    if (rg_lane() == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&bbox[cid * 6 + a], rg_f2ord(mn[a]));
+            atomicMax(&bbox[cid * 6 + 3 + a], rg_f2ord(mx[a]));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, const int* __restrict__ seg_off, int n_clouds,
                                               int* __restrict__ pcid, int* __restrict__ bbox)
 {
     const int n = seg_off[n_clouds];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    int cid = -1;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (live) {
-        cid = rg_find_segment(seg_off, n_clouds, i);
-        pcid[i] = cid;
-        x = xyz[3 * (size_t)i]; y = xyz[3 * (size_t)i + 1]; z = xyz[3 * (size_t)i + 2];
-    }
-    // wave-uniform cloud -> one set of atomics per wave
-    const int cid0 = __shfl(cid, 0, RG_WAVE);
-    const bool uniform = __all(cid == cid0) && cid0 >= 0;
-    if (uniform) {
-        float mn[3] = {x, y, z}, mx[3] = {x, y, z};
+    const int base = blockIdx.x * (256 * BBOX_ITEMS) + threadIdx.x;
+    int cur = -1;   // cloud of the running box (wave-uniform)
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = 0; j < BBOX_ITEMS; j++) {
+        const int i = base + j * 256;
+        const bool live = i < n;
+        int cid = -1;
+        float p[3] = {0.f, 0.f, 0.f};
+        if (live) {
+            cid = rg_find_segment(seg_off, n_clouds, i);
+            pcid[i] = cid;
+            p[0] = xyz[3 * (size_t)i]; p[1] = xyz[3 * (size_t)i + 1]; p[2] = xyz[3 * (size_t)i + 2];
+        }
+        const int cid0 = __shfl(cid, 0, RG_WAVE);
+        const bool uniform = __all(cid == cid0) && cid0 >= 0;
+        if (uniform) {
+            if (cid0 != cur) {
+                bbox_flush(cur, mn, mx, bbox);
+                cur = cid0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, RG_WAVE));
-                mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, RG_WAVE));
+                for (int a = 0; a < 3; a++) { mn[a] = INFINITY; mx[a] = -INFINITY; }
             }
-        if (rg_lane() == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { mn[a] = fminf(mn[a], p[a]); mx[a] = fmaxf(mx[a], p[a]); }
+        } else if (live) {   // wave straddles a cloud boundary (or the tail): per-lane atomics
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                atomicMin(&bbox[cid0 * 6 + a], rg_f2ord(mn[a]));
-                atomicMax(&bbox[cid0 * 6 + 3 + a], rg_f2ord(mx[a]));
+                atomicMin(&bbox[cid * 6 + a], rg_f2ord(p[a]));
+                atomicMax(&bbox[cid * 6 + 3 + a], rg_f2ord(p[a]));
             }
         }
-    } else if (live) {
-        atomicMin(&bbox[cid * 6 + 0], rg_f2ord(x)); atomicMin(&bbox[cid * 6 + 1], rg_f2ord(y));
-        atomicMin(&bbox[cid * 6 + 2], rg_f2ord(z)); atomicMax(&bbox[cid * 6 + 3], rg_f2ord(x));
-        atomicMax(&bbox[cid * 6 + 4], rg_f2ord(y)); atomicMax(&bbox[cid * 6 + 5], rg_f2ord(z));
     }
+    bbox_flush(cur, mn, mx, bbox);
 }
 
 // voxel key of every point, exactly as grid_subsampling.cpp:25-31,53-56 computes it (float32, no contraction)
@@ -562,7 +584,7 @@ int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int
     (void)hipMemsetAsync(cnt, 0, sizeof(int) * T, st);
     (void)hipMemsetAsync(fill, 0, sizeof(int) * T, st);
     k_init_bbox<<<rg_cdiv(n_clouds * 6, 256), 256, 0, st>>>(bbox, n_clouds);
-    k_bbox<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
+    k_bbox<<<rg_cdiv(n_cap, 256 * BBOX_ITEMS), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
     k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, pkey);
     k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, T - 1, slot_of, first, cnt);
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);

@@ -125,9 +125,10 @@ class KPConv(nn.Module):
         kp = load_kernels(radius, kernel_size, dimension=p_dim, fixed=fixed_kernel_points)
         self.kernel_points = nn.Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)   # :266
 
-    def forward(self, q_pts, s_pts, neighb_inds, x):
+    def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None):
         w = self.weights.detach().view(self.K * self.in_channels, self.out_channels)
-        return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent)
+        return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent,
+                          x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off)
 
 
 class UnaryBlock(nn.Module):
@@ -141,9 +142,10 @@ class UnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_dim, out_dim, bias=False)
         self._cache = {}
 
-    def linear(self, x):
+    def linear(self, x, a_stats=None, a_seg_off=None):
+        """The Linear alone; its InstanceNorm (+LeakyReLU) is folded into whichever kernel consumes the result."""
         wt = _prepared(self._cache, 'w', self.mlp.weight, lambda w: w.t().contiguous())
-        return ops.gemm(x, wt)
+        return ops.gemm(x, wt, a_stats=a_stats, a_seg_off=a_seg_off)
 
     def forward(self, x, seg_off, max_len):
         y = self.linear(x)
@@ -205,11 +207,16 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, meta):
         strided = 'strided' in self.block_name
         v = _LevelView(meta, self.layer_ind, strided)
-        x = self.unary1(features, v.seg_pre, v.max_pre) if isinstance(self.unary1, UnaryBlock) else features   # :722
-        x = self.KPConv(v.q_pts, v.s_pts, v.inds, x)                                                          # :726
+        # unary1 = Linear -> IN -> LReLU (:722): the IN+LReLU tail is applied on the fly inside the KPConv gather
+        if isinstance(self.unary1, UnaryBlock):
+            x = self.unary1.linear(features)
+            x_st = ops.instnorm_stats(x, v.seg_pre, v.max_pre)
+        else:
+            x, x_st = features, None
+        x = self.KPConv(v.q_pts, v.s_pts, v.inds, x, x_stats=x_st, s_seg_off=v.seg_pre, q_seg_off=v.seg_post)     # :726
+        # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
         st = ops.instnorm_stats(x, v.seg_post, v.max_post)
-        x = ops.instnorm_apply(x, v.seg_post, v.max_post, st, lrelu=True, out=x)                              # :727
-        y = self.unary2.linear(x)                                                                             # :730
+        y = self.unary2.linear(x, a_stats=st, a_seg_off=v.seg_post)
         y_st = ops.instnorm_stats(y, v.seg_post, v.max_post)
         shortcut = ops.maxpool(features, v.inds) if strided else features                                     # :734-737
         sc_st = None

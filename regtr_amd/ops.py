@@ -53,18 +53,23 @@ class CellGrid:
 
 
 # ------------------------------------------------------------------------------------------------ dense
-def gemm(a, b_kn, bias=None, row_div=None, residual=None, relu=False, out=None):
-    """a (M,K) @ b_kn (K,N) with the fused epilogue of regtr_gemm_f32.  `a` may be a row-strided view."""
+def gemm(a, b_kn, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1):
+    """a (M,K) @ b_kn (K,N) with the fused epilogue of regtr_gemm_f32.  `a` may be a row-strided view.
+    a_stats (n_seg,K,2) + a_seg_off: A is read as LeakyReLU(InstanceNorm(a)) (per-cloud stats) on the fly."""
+    L = _lib.lib()
     M, K = a.shape
     Kb, N = b_kn.shape
     assert K == Kb and a.stride(1) == 1 and b_kn.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldr = residual.stride(0) if residual is not None else 0
-    check(_lib.lib().regtr_gemm_f32(a.data_ptr(), a.stride(0) if M > 1 else K, ptr(b_kn), N, out.data_ptr(),
-                                    out.stride(0) if M > 1 else N, M, N, K, ptr(bias), ptr(row_div),
-                                    residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
-                                    stream()), 'regtr_gemm_f32')
+    nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
+    ws = _ws(nb, a.device) if nb else None
+    n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
+    check(L.regtr_gemm_f32(a.data_ptr(), a.stride(0) if M > 1 else K, ptr(b_kn), N, out.data_ptr(),
+                           out.stride(0) if M > 1 else N, M, N, K, ptr(bias), ptr(row_div),
+                           residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
+                           ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_f32')
     return out
 
 
@@ -92,20 +97,25 @@ def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
 
 
 # ------------------------------------------------------------------------------------------------ KPConv encoder
-def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent):
+def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None, slope=0.1):
     """KPConv.forward (kpconv_blocks.py:269-414), non-deformable / linear / sum.
-    nbr (Nq,H) i32, x (Ns,Cin), w_flat (KP*Cin, Cout) -> (Nq, Cout)."""
+    nbr (Nq,H) i32, x (Ns,Cin), w_flat (KP*Cin, Cout) -> (Nq, Cout).
+    x_stats (n_clouds,Cin,2): the input features are LeakyReLU(InstanceNorm(x)) applied on the fly (the tail of the
+    preceding UnaryBlock, kpconv_blocks.py:556-561), with s_seg_off / q_seg_off the support / query cloud offsets."""
     L = _lib.lib()
     nq, H = nbr.shape
     ns, Cin = x.shape
     KP = kernel_points.shape[0]
     dev = x.device
+    n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
     flag = torch.empty(ns, dtype=torch.float32, device=dev)
-    check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(flag), stream()), 'regtr_rowsum_positive')
+    check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), ptr(s_seg_off) if x_stats is not None else None, n_seg,
+                                  slope, ptr(flag), stream()), 'regtr_rowsum_positive')
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
     check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, ptr(nbr), H, ptr(x), Cin, ptr(flag),
-                                ptr(kernel_points), KP, float(extent), ptr(wf), ptr(num), stream()),
+                                ptr(kernel_points), KP, float(extent), ptr(x_stats),
+                                ptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
           'regtr_kpconv_gather')
     return gemm(wf, w_flat, row_div=num)
 

@@ -197,6 +197,35 @@ def test_kpconv_vs_oracle(Cin, Cout, H):
     assert (out.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_fused_instnorm_paths_vs_oracle():
+    """InstanceNorm+LeakyReLU folded into the KPConv gather (unary1 tail) and into the GEMM A load (conv tail)."""
+    from oracle import native, regtr_ref
+    from regtr_amd.kernel_points import K015_CENTER
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    clouds = [synth_cloud(rng, 900), synth_cloud(rng, 1400) + 7.0]
+    s = np.concatenate(clouds); lens = np.array([900, 1400], np.int32)
+    q, ql = native.grid_subsample(s, lens, 0.08)
+    r, Cin, Cout = 0.15, 64, 48
+    idx, _, _ = native.radius_neighbors(q, s, ql, lens, r, 40)
+    y = (rng.standard_normal((len(s), Cin)) * rng.uniform(0.2, 3, Cin) + rng.uniform(-2, 2, Cin)).astype(np.float32)
+    w = (rng.standard_normal((15, Cin, Cout)) / 30).astype(np.float32)
+    kp = (K015_CENTER * r).astype(np.float32)
+    L = torch.from_numpy(lens.astype(np.int64))
+    x_ref = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(y), L), 0.1)
+    ref = regtr_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64)), x_ref,
+                           torch.from_numpy(w), torch.from_numpy(kp), 0.12)
+    st = ops.instnorm_stats(to_dev(y), seg_of(lens), int(lens.max()))
+    out = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), to_dev(y), to_dev(w.reshape(15 * Cin, Cout)), to_dev(kp), 0.12,
+                     x_stats=st, s_seg_off=seg_of(lens), q_seg_off=seg_of(ql))
+    assert (out.cpu() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+    # GEMM with the normalisation folded into the A operand
+    w2 = (rng.standard_normal((Cin, 96)) / 8).astype(np.float32)
+    ref2 = x_ref @ torch.from_numpy(w2)
+    out2 = ops.gemm(to_dev(y), to_dev(w2), a_stats=st, a_seg_off=seg_of(lens))
+    assert (out2.cpu() - ref2).abs().max() < 3e-5 * max(1.0, ref2.abs().max().item())
+
+
 def test_maxpool_instnorm_vs_oracle():
     from oracle import native, regtr_ref
     ops = _ops()
