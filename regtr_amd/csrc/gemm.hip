@@ -8,7 +8,7 @@
 //
 // Tiles: 256-thread workgroups of 4 waves, one 32x32 accumulator per wave, arranged 2x2 (64x64 tile) or, for thin
 // outputs (N <= 32: the level-0 KPConv contraction and unary1), 4x1 (128x32 tile) so no MFMA work is spent on
-// padding columns.  BK = 16, LDS double-buffered with the next tile's global loads issued before the current MFMAs.
+// padding columns.  BK = 32, LDS double-buffered with the next tile's global loads issued before the current MFMAs.
 // Small-M / deep-K problems (the 750-token transformer and level-3 KPConv contractions: a few hundred tiles with a
 // serial chain of K/2 MFMAs each) are split along K across workgroups; partial tiles go to a workspace and a second
 // kernel reduces them in fixed order (deterministic) and applies the epilogue.
@@ -21,7 +21,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int LDA_S = BK + 1;   // odd stride: A-fragment column reads hit 32 distinct banks
 
 struct GemmArgs {
@@ -35,13 +35,14 @@ struct GemmArgs {
 
 template <bool ALIGNED, int BM, int BN>
 __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, int k_end,
-                                           float (&ra)[BM / 64][4], float (&rb)[4], const int* row_seg)
+                                           float (&ra)[BM * BK / 1024][4], float (&rb)[BK * BN / 1024][4], const int* row_seg)
 {
     const int t = threadIdx.x;
+    constexpr int KV = BK / 4;                      // float4 per A row
 #pragma unroll
-    for (int i = 0; i < BM / 64; i++) {   // A: BM rows x 16 k -> (row = idx/4, k4 = (idx%4)*4)
+    for (int i = 0; i < BM * BK / 1024; i++) {      // A: BM rows x BK k -> (row = idx / KV, k4 = (idx % KV) * 4)
         const int idx = t + i * 256;
-        const int row = m0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+        const int row = m0 + idx / KV, k = k0 + (idx % KV) * 4;
         if (ALIGNED) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < g.M && k < k_end) v = *(const float4*)(g.A + (size_t)row * g.lda + k);
@@ -61,20 +62,20 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
                 }
         }
     }
-    {   // B: 16 k x BN n -> (k = t / (BN/4), n4 = (t % (BN/4)) * 4)
-        constexpr int NV = BN / 4;
-        const int k = k0 + t / NV, n = n0 + (t % NV) * 4;
-        rb[0] = rb[1] = rb[2] = rb[3] = 0.f;
-        if (t < BK * NV) {
-            if (ALIGNED) {
-                if (k < k_end && n < g.N) {
-                    const float4 v = *(const float4*)(g.B + (size_t)k * g.ldb + n);
-                    rb[0] = v.x; rb[1] = v.y; rb[2] = v.z; rb[3] = v.w;
-                }
-            } else {
+    constexpr int NV = BN / 4;                      // float4 per B row
 #pragma unroll
-                for (int j = 0; j < 4; j++) rb[j] = (k < k_end && n + j < g.N) ? g.B[(size_t)k * g.ldb + n + j] : 0.f;
+    for (int i = 0; i < BK * BN / 1024; i++) {      // B: BK k x BN n -> (k = idx / NV, n4 = (idx % NV) * 4)
+        const int idx = t + i * 256;
+        const int k = k0 + idx / NV, n = n0 + (idx % NV) * 4;
+        rb[i][0] = rb[i][1] = rb[i][2] = rb[i][3] = 0.f;
+        if (ALIGNED) {
+            if (k < k_end && n < g.N) {
+                const float4 v = *(const float4*)(g.B + (size_t)k * g.ldb + n);
+                rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
             }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) rb[i][j] = (k < k_end && n + j < g.N) ? g.B[(size_t)k * g.ldb + n + j] : 0.f;
         }
     }
 }
@@ -94,11 +95,12 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    int row_seg[BM / 64];
+    constexpr int AV = BM * BK / 1024, BV = BK * BN / 1024, KV = BK / 4, NV = BN / 4;
+    int row_seg[AV];
 #pragma unroll
-    for (int i = 0; i < BM / 64; i++) {
+    for (int i = 0; i < AV; i++) {
         row_seg[i] = 0;
-        const int row = m0 + ((t + i * 256) >> 2);
+        const int row = m0 + (t + i * 256) / KV;
         if (g.a_stats && row < g.M) row_seg[i] = rg_find_segment(g.a_seg_off, g.n_seg, row);
     }
 
@@ -106,19 +108,20 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    float ra[BM / 64][4], rb[4];
+    float ra[AV][4], rb[BV][4];
     load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra, rb, row_seg);
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < BM / 64; i++) {
+        for (int i = 0; i < AV; i++) {
             const int idx = t + i * 256;
-            float* a = &As[buf][(idx >> 2) * LDA_S + (idx & 3) * 4];
+            float* a = &As[buf][(idx / KV) * LDA_S + (idx % KV) * 4];
             a[0] = ra[i][0]; a[1] = ra[i][1]; a[2] = ra[i][2]; a[3] = ra[i][3];
         }
-        constexpr int NV = BN / 4;
-        if (t < BK * NV) {
-            float* b = &Bs[buf][(t / NV) * LDB_S + (t % NV) * 4];
-            b[0] = rb[0]; b[1] = rb[1]; b[2] = rb[2]; b[3] = rb[3];
+#pragma unroll
+        for (int i = 0; i < BV; i++) {
+            const int idx = t + i * 256;
+            float* b = &Bs[buf][(idx / NV) * LDB_S + (idx % NV) * 4];
+            b[0] = rb[i][0]; b[1] = rb[i][1]; b[2] = rb[i][2]; b[3] = rb[i][3];
         }
     };
     stage(0);

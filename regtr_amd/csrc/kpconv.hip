@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
         const int k = lane & (KP_PAD - 1);
         const bool kvalid = k < g.KP;
         const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+        const float inv_extent = 1.0f / g.extent;
         for (int e = lane; e < QW * H * KP_PAD; e += RG_WAVE) {
             const int qh = e >> 4;   // (qi*H + h)
             const float dx = rel_s[3 * qh] - kx, dy = rel_s[3 * qh + 1] - ky, dz = rel_s[3 * qh + 2] - kz;
@@ -101,7 +102,8 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
 #pragma clang fp contract(off)
                 d2 = (dx * dx + dy * dy) + dz * dz;                               // kpconv_blocks.py:326-329
             }
-            float wv = 1.f - sqrtf(d2) / g.extent;                                // :368
+            // :368  1 - sqrt(d2)/extent with the hardware sqrt (1 ulp) and a precomputed reciprocal: |error| <~ 2e-7
+            float wv = 1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent;
             w_s[e] = (kvalid && wv > 0.f) ? wv : 0.f;
         }
     }
@@ -113,15 +115,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     const float* wq = w_s + (size_t)qi * H * KP_PAD;
     const int* iq = idx_s + qi * H;
     const int Cin = g.Cin;
-    if (Cin == 1) {
-        // single input channel (first encoder block): lanes = kernel points, features already staged in LDS
-        if (LQ == 16 && cl < g.KP) {
-            const float* xq = xs_s + qi * H;
-            float acc = 0.f;
-            for (int h = 0; h < H; h++) acc = fmaf(wq[h * KP_PAD + cl], xq[h], acc);
-            g.wf[(size_t)q * g.KP + cl] = acc;
-        }
-    } else {
+    {
         const float2* st = nullptr;
         if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
         for (int c = cl; c < Cin; c += LQ) {
@@ -130,21 +124,31 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
             for (int k = 0; k < KP_PAD; k++) acc[k] = 0.f;
             float mu = 0.f, rs = 1.f;
             if (st) { mu = st[c].x; rs = st[c].y; }
-            for (int h = 0; h < H; h++) {
-                const int idx = iq[h];
-                float xv = 0.f;                                                    // zero shadow feature (:388)
-                if (idx < g.ns) {
-                    xv = g.x[(size_t)idx * Cin + c];
-                    if (st) { xv = (xv - mu) * rs; xv = xv > 0.f ? xv : xv * g.slope; }
-                }
-                const float4* w4 = (const float4*)(wq + h * KP_PAD);
+            // neighbour rows are fetched 8 at a time before any of them is consumed: 8 independent gathers in flight per
+            // lane hide the L2 / Infinity-Cache latency that a load-use chain per neighbour would expose
+            for (int h0 = 0; h0 < H; h0 += 8) {
+                float xv[8];
 #pragma unroll
-                for (int j = 0; j < KP_PAD / 4; j++) {
-                    const float4 wv = w4[j];
-                    acc[4 * j + 0] = fmaf(wv.x, xv, acc[4 * j + 0]);
-                    acc[4 * j + 1] = fmaf(wv.y, xv, acc[4 * j + 1]);
-                    acc[4 * j + 2] = fmaf(wv.z, xv, acc[4 * j + 2]);
-                    acc[4 * j + 3] = fmaf(wv.w, xv, acc[4 * j + 3]);
+                for (int u = 0; u < 8; u++) {
+                    const int h = h0 + u;
+                    const int idx = h < H ? iq[h] : g.ns;
+                    xv[u] = idx < g.ns ? g.x[(size_t)idx * Cin + c] : 0.f;          // zero shadow feature (:388)
+                    if (st && idx < g.ns) { const float t = (xv[u] - mu) * rs; xv[u] = t > 0.f ? t : t * g.slope; }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int h = h0 + u;
+                    if (h < H) {
+                        const float4* w4 = (const float4*)(wq + h * KP_PAD);
+#pragma unroll
+                        for (int j = 0; j < KP_PAD / 4; j++) {
+                            const float4 wv = w4[j];
+                            acc[4 * j + 0] = fmaf(wv.x, xv[u], acc[4 * j + 0]);
+                            acc[4 * j + 1] = fmaf(wv.y, xv[u], acc[4 * j + 1]);
+                            acc[4 * j + 2] = fmaf(wv.z, xv[u], acc[4 * j + 2]);
+                            acc[4 * j + 3] = fmaf(wv.w, xv[u], acc[4 * j + 3]);
+                        }
+                    }
                 }
             }
             float* o = g.wf + (size_t)q * g.KP * Cin + c;
@@ -161,6 +165,57 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     }
 }
 
+// Cin == 1 (first encoder block, features = ones): no channel dimension to spread over lanes, so lanes are
+// (query, kernel point) pairs: 4 queries x 16 kernel points per wave, each lane walks its query's neighbours once and
+// accumulates influence x feature directly -- no influence tile in LDS, 6 floats of LDS per neighbour instead of 22.
+__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(GatherArgs g)
+{
+    constexpr int QW = 4;
+    extern __shared__ __align__(16) float smem[];
+    const int wave = threadIdx.x >> 6, lane = rg_lane();
+    const int H = g.H;
+    float* rel_s = smem + (size_t)wave * QW * H * 5;      // rel[QW][H][3] | x[QW][H] | flag[QW][H]
+    float* xs_s = rel_s + QW * H * 3;
+    float* flg_s = xs_s + QW * H;
+    const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
+    if (q0 >= g.nq) return;
+    for (int e = lane; e < QW * H; e += RG_WAVE) {
+        const int qi = e / H, h = e - qi * H, q = q0 + qi;
+        float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f, x1 = 0.f;
+        if (q < g.nq) {
+            const int idx = g.nbr[(size_t)q * H + h];
+            float sx = 1e6f, sy = 1e6f, sz = 1e6f;
+            if (idx < g.ns) {
+                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
+                f = g.flag[idx]; x1 = g.x[idx];
+            }
+            rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
+        }
+        rel_s[3 * e] = rx; rel_s[3 * e + 1] = ry; rel_s[3 * e + 2] = rz; xs_s[e] = x1; flg_s[e] = f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int qi = lane >> 4, k = lane & 15, q = q0 + qi;
+    if (q >= g.nq) return;
+    const bool kvalid = k < g.KP;
+    const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+    const float inv_extent = 1.0f / g.extent;
+    float acc = 0.f, cnt = 0.f;
+    for (int h = 0; h < H; h++) {
+        const int e = qi * H + h;
+        const float dx = rel_s[3 * e] - kx, dy = rel_s[3 * e + 1] - ky, dz = rel_s[3 * e + 2] - kz;
+        float d2;
+        {
+#pragma clang fp contract(off)
+            d2 = (dx * dx + dy * dy) + dz * dz;
+        }
+        const float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);
+        acc = fmaf(wv, xs_s[e], acc);
+        cnt += flg_s[e];
+    }
+    if (kvalid) g.wf[(size_t)q * g.KP + k] = acc;
+    if (k == 0) g.num[q] = fmaxf(cnt, 1.f);
+}
+
 // out[q, c] = max_h x_pad[nbr[q, h], c]   with a zero shadow row   (kpconv_blocks.py:127-143)
 __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
                                                         int nq, int H, float* __restrict__ out)
@@ -171,11 +226,18 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
     const int* row = nbr + (size_t)q * H;
     for (int c = lane * 4; c < C; c += RG_WAVE * 4) {
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        for (int h = 0; h < H; h++) {
-            const int idx = row[h];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < ns) v = *(const float4*)(x + (size_t)idx * C + c);
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        for (int h0 = 0; h0 < H; h0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int idx = h0 + u < H ? row[h0 + u] : -1;
+                v[u] = m;                                                    // out-of-range slot: neutral
+                if (idx >= 0) v[u] = idx < ns ? *(const float4*)(x + (size_t)idx * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+            }
         }
         *(float4*)(out + (size_t)q * C + c) = m;
     }
@@ -209,6 +271,13 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
                  nq, ns, H, Cin, KP, n_seg, extent, slope};
     hipStream_t st = (hipStream_t)stream;
+    if (Cin == 1) {
+        if (x_stats) return RG_ERR_ARG;
+        const size_t lds1 = (size_t)GATHER_WAVES * 4 * H * 5 * sizeof(float);
+        k_kpconv_gather_c1<<<rg_cdiv(nq, GATHER_WAVES * 4), GATHER_WAVES * RG_WAVE, lds1, st>>>(g);
+        RG_RETURN_IF_LAUNCH_FAILED();
+        return RG_OK;
+    }
     const int LQ = Cin <= 16 ? 16 : (Cin <= 32 ? 32 : 64);
     const int QW = RG_WAVE / LQ;
     const size_t lds = (size_t)GATHER_WAVES * ((QW * H * (KP_PAD + 6) + 3) & ~3) * sizeof(float);
