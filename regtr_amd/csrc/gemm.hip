@@ -108,9 +108,11 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
 
-    float ra[AV][4], rb[BV][4];
-    load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra, rb, row_seg);
-    auto stage = [&](int buf) {
+    // Two register stages (R0/R1) feed two LDS buffers: the global loads of tile t+2 are issued before the MFMAs of
+    // tile t and only written to LDS after the MFMAs of tile t+1, so every load has ~2 tiles of matrix-core work
+    // (>= 2048 cycles) to cover its L2 / Infinity-Cache latency even with a single workgroup per CU.
+    float ra0[AV][4], rb0[BV][4], ra1[AV][4], rb1[BV][4];
+    auto stage = [&](int buf, float (&ra)[AV][4], float (&rb)[BV][4]) {
 #pragma unroll
         for (int i = 0; i < AV; i++) {
             const int idx = t + i * 256;
@@ -124,18 +126,28 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
             b[0] = rb[i][0]; b[1] = rb[i][1]; b[2] = rb[i][2]; b[3] = rb[i][3];
         }
     };
-    stage(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; kt++) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 1) * BK, k_end, ra, rb, row_seg);
-        const float* a = &As[cur][(wm * 32 + l31) * LDA_S + hi];
-        const float* b = &Bs[cur][hi * LDB_S + wn * 32 + l31];
+    auto compute = [&](int buf) {
+        const float* a = &As[buf][(wm * 32 + l31) * LDA_S + hi];
+        const float* b = &Bs[buf][hi * LDB_S + wn * 32 + l31];
 #pragma unroll
         for (int s = 0; s < BK / 2; s++)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], b[2 * s * LDB_S], acc, 0, 0, 0);
-        if (kt + 1 < nk) stage(cur ^ 1);
+    };
+    load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra0, rb0, row_seg);
+    if (nk > 1) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + BK, k_end, ra1, rb1, row_seg);
+    stage(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile kt lives in LDS buffer 0
+        if (kt + 2 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 2) * BK, k_end, ra0, rb0, row_seg);
+        compute(0);
+        if (kt + 1 < nk) stage(1, ra1, rb1);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd tile kt + 1 lives in LDS buffer 1
+        if (kt + 3 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 3) * BK, k_end, ra1, rb1, row_seg);
+        compute(1);
+        if (kt + 2 < nk) stage(0, ra0, rb0);
         __syncthreads();
     }
 
