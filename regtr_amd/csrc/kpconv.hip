@@ -165,6 +165,131 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Matrix-core gather.  For one query the kernel-point correlation  WF[k, c] = sum_h w[h, k] * x[n_h, c]  is a
+// [16 x H] x [H x Cin] product, so it runs on v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain over h in order):
+//   A operand  lane (k = l & 15, hh = l >> 4)  holds  w[h = 4 j + hh][k]      -- computed by that very lane from the
+//              centred neighbour offset and ITS kernel point, so influences go from the VALU straight into the MFMA
+//              with no LDS tile and no broadcast reads;
+//   B operand  lane (c = l & 15, hh = l >> 4)  holds  x[n_{4 j + hh}][c0 + c] -- one dword of a gathered row; all
+//              J x (Cin/16) gathers of a query are issued before the first MFMA, so tens of independent loads per lane
+//              are in flight and L2 / Infinity-Cache latency disappears behind them;
+//   D          lane holds WF[k = 4 hh + r][c0 + c], r = 0..3, written straight to the weighted-feature matrix.
+// The VALU only computes 10-16 influences per lane per query (hardware sqrt); the 15 x H x Cin multiply-adds run on
+// the matrix pipe at its full f32 rate while other waves' loads and influence maths overlap.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int MG_QPW = 4;      // queries handled one after another by each wave
+
+template <int J, int MG_CB>    // J = ceil(H / 4) neighbour groups (H <= 4 J); MG_CB 16-channel blocks per pass
+__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(GatherArgs g)
+{
+    constexpr int HP = 4 * J;
+    __shared__ float rel_sh[GATHER_WAVES][HP * 3];
+    __shared__ int idx_sh[GATHER_WAVES][HP];
+    __shared__ float flg_sh[GATHER_WAVES][HP];
+    const int wave = threadIdx.x >> 6, lane = rg_lane();
+    const int k = lane & 15, hh = lane >> 4;
+    const int H = g.H, Cin = g.Cin, ns = g.ns;
+    float* rel_s = rel_sh[wave];
+    int* idx_s = idx_sh[wave];
+    float* flg_s = flg_sh[wave];
+    const bool kvalid = k < g.KP;
+    const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+    const float inv_extent = 1.0f / g.extent;
+
+    const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
+    for (int qq = 0; qq < MG_QPW; qq++) {
+        const int q = qbase + qq;
+        if (q >= g.nq) return;          // wave-uniform
+        // ---- neighbours of this query: lanes = h
+        __builtin_amdgcn_wave_barrier();
+        if (lane < HP) {
+            int idx = ns;
+            float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f;
+            if (lane < H) idx = g.nbr[(size_t)q * H + lane];
+            float sx = 1e6f, sy = 1e6f, sz = 1e6f;                   // shadow support point (kpconv_blocks.py:309)
+            if (idx < ns) {
+                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
+                f = g.flag[idx];
+            }
+            rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
+            rel_s[3 * lane] = rx; rel_s[3 * lane + 1] = ry; rel_s[3 * lane + 2] = rz;
+            idx_s[lane] = idx; flg_s[lane] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- influences of kernel point k for neighbours h = 4 j + hh   (the A operands)
+        float w[J];
+        int nidx[J];
+        float fsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int h = 4 * j + hh;
+            const float dx = rel_s[3 * h] - kx, dy = rel_s[3 * h + 1] - ky, dz = rel_s[3 * h + 2] - kz;
+            float d2;
+            {
+#pragma clang fp contract(off)
+                d2 = (dx * dx + dy * dy) + dz * dz;                                   // kpconv_blocks.py:326-329
+            }
+            const float wv = 1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent;           // :368
+            w[j] = (kvalid && wv > 0.f) ? wv : 0.f;
+            nidx[j] = idx_s[h];
+            fsum += flg_s[h];
+        }
+        // normaliser: every 16-lane group saw the flags of its hh; combine the four groups   (:409-411)
+        fsum += __shfl_xor(fsum, 16, RG_WAVE);
+        fsum += __shfl_xor(fsum, 32, RG_WAVE);
+        if (lane == 0) g.num[q] = fmaxf(fsum, 1.f);
+
+        const float2* st = nullptr;
+        if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
+        float* wf_q = g.wf + (size_t)q * g.KP * Cin;
+        // ---- channel passes of up to 64 channels
+        for (int c0 = 0; c0 < Cin; c0 += 16 * MG_CB) {
+            float xv[J][MG_CB];
+#pragma unroll
+            for (int j = 0; j < J; j++)
+#pragma unroll
+                for (int cb = 0; cb < MG_CB; cb++) {
+                    const int c = c0 + cb * 16 + k;
+                    xv[j][cb] = (nidx[j] < ns && c < Cin) ? g.x[(size_t)nidx[j] * Cin + c] : 0.f;   // zero shadow row (:388)
+                }
+            if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock
+#pragma unroll
+                for (int cb = 0; cb < MG_CB; cb++) {
+                    const int c = c0 + cb * 16 + k;
+                    if (c < Cin) {
+                        const float2 ms = st[c];
+#pragma unroll
+                        for (int j = 0; j < J; j++)
+                            if (nidx[j] < ns) { const float t = (xv[j][cb] - ms.x) * ms.y; xv[j][cb] = t > 0.f ? t : t * g.slope; }
+                    }
+                }
+            }
+            floatx4 acc[MG_CB];
+#pragma unroll
+            for (int cb = 0; cb < MG_CB; cb++) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < J; j++)
+#pragma unroll
+                for (int cb = 0; cb < MG_CB; cb++)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], xv[j][cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < MG_CB; cb++) {
+                const int c = c0 + cb * 16 + k;
+                if (c < Cin) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int kk = 4 * hh + r;
+                        if (kk < g.KP) wf_q[(size_t)kk * Cin + c] = acc[cb][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Cin == 1 (first encoder block, features = ones): no channel dimension to spread over lanes, so lanes are
 // (query, kernel point) pairs: 4 queries x 16 kernel points per wave, each lane walks its query's neighbours once and
 // accumulates influence x feature directly -- no influence tile in LDS, 6 floats of LDS per neighbour instead of 22.
@@ -275,6 +400,18 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
         if (x_stats) return RG_ERR_ARG;
         const size_t lds1 = (size_t)GATHER_WAVES * 4 * H * 5 * sizeof(float);
         k_kpconv_gather_c1<<<rg_cdiv(nq, GATHER_WAVES * 4), GATHER_WAVES * RG_WAVE, lds1, st>>>(g);
+        RG_RETURN_IF_LAUNCH_FAILED();
+        return RG_OK;
+    }
+    if (Cin >= 16 && H <= 64) {   // matrix-core path
+        const int grid_m = rg_cdiv(nq, GATHER_WAVES * MG_QPW);
+        const int cb = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
+        const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
+#define RG_LAUNCH_MG(JJ, CC) k_kpconv_gather_mfma<JJ, CC><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g)
+        if (J == 10) { if (cb == 4) RG_LAUNCH_MG(10, 4); else if (cb == 2) RG_LAUNCH_MG(10, 2); else RG_LAUNCH_MG(10, 1); }
+        else if (J == 13) { if (cb == 4) RG_LAUNCH_MG(13, 4); else if (cb == 2) RG_LAUNCH_MG(13, 2); else RG_LAUNCH_MG(13, 1); }
+        else { if (cb == 4) RG_LAUNCH_MG(16, 4); else if (cb == 2) RG_LAUNCH_MG(16, 2); else RG_LAUNCH_MG(16, 1); }
+#undef RG_LAUNCH_MG
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }
