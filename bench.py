@@ -29,6 +29,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH
 # ----------------------------------------------------------------------------------------------------------------
 # synthetic 3DMatch-like pairs
 # ----------------------------------------------------------------------------------------------------------------
+def _morton(ijk):
+    ijk = ijk - ijk.min(0)
+    key = np.zeros(len(ijk), np.int64)
+    for b in range(16):
+        for a in range(3):
+            key |= ((ijk[:, a] >> b) & 1) << (3 * b + a)
+    return key
+
+
 def _scene_once(rng, side, voxel):
     surf = []
 
@@ -54,7 +63,10 @@ def _scene_once(rng, side, voxel):
     out = np.zeros((len(cnt), 3))
     np.add.at(out, inv.ravel(), p)
     out /= cnt[:, None]
-    return out[rng.permutation(len(out))], X
+    out = out[np.argsort(_morton(np.floor(out / (4 * voxel)).astype(np.int64)), kind='stable')]
+    # rows are in Morton order of 10 cm blocks: real 3DMatch fragments are spatially coherent too (median |i - j| between
+    # neighbours is ~80 rows on the shipped red-kitchen clouds); --shuffle gives the adversarial random order
+    return out, X
 
 
 def synth_scene(rng, target_pts, voxel=0.025):
@@ -78,7 +90,7 @@ def random_se3(rng, rot_deg=45.0, trans=0.5):
     return R, t
 
 
-def synth_pair(pair_id, pts_per_cloud=20000):
+def synth_pair(pair_id, pts_per_cloud=20000, shuffle=False):
     rng = np.random.default_rng(1000 + pair_id)
     scene, X = synth_scene(rng, int(pts_per_cloud / 0.72))
     src = scene[scene[:, 0] < 0.72 * X]
@@ -86,6 +98,8 @@ def synth_pair(pair_id, pts_per_cloud=20000):
     R, t = random_se3(rng)
     tgt = tgt @ R.T + t + rng.normal(scale=0.005, size=tgt.shape)        # augment_noise 0.005 (3dmatch.yaml:7)
     src = src + rng.normal(scale=0.005, size=src.shape)
+    if shuffle:
+        src, tgt = src[rng.permutation(len(src))], tgt[rng.permutation(len(tgt))]
     return src.astype(np.float32), tgt.astype(np.float32)
 
 
@@ -186,6 +200,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--pairs', type=int, default=16, help='pairs per step per GPU (one forward)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
+    ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -210,7 +225,7 @@ def main():
     torch.manual_seed(0); np.random.seed(0)
     model = RegTR(cfg).to(dev).eval()
 
-    pairs = [synth_pair(rank * 100003 + i, args.points) for i in range(args.pairs)]
+    pairs = [synth_pair(rank * 100003 + i, args.points, args.shuffle) for i in range(args.pairs)]
     batch = {'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in pairs],
              'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in pairs]}
     pair_ids = torch.arange(args.pairs, device=dev, dtype=torch.int32) + rank * args.pairs
