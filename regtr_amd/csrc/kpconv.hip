@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
 // the matrix pipe at its full f32 rate while other waves' loads and influence maths overlap.
 // ------------------------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int MG_QPW = 4;      // queries handled one after another by each wave
+constexpr int MG_QPW = 8;      // queries handled one after another by each wave
 
 template <int J, int MG_CB>    // J = ceil(H / 4) neighbour groups (H <= 4 J); MG_CB 16-channel blocks per pass
 __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(GatherArgs g)
@@ -199,24 +199,37 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
     const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
     const float inv_extent = 1.0f / g.extent;
 
+    // Software pipeline over the wave's queries: the index row of query q+2 and the neighbour coordinates of query q+1
+    // are requested while query q is in its gather / MFMA phase, so the idx -> xyz -> features dependency chain of one
+    // query overlaps the matrix work of the previous one instead of being exposed three memory latencies deep.
     const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
+    if (qbase >= g.nq) return;
+    auto load_idx = [&](int q) -> int { return (q < g.nq && lane < H) ? g.nbr[(size_t)q * H + lane] : ns; };
+    struct Nb { float rx, ry, rz, f; };
+    auto load_nb = [&](int q, int idx) -> Nb {
+        Nb n{1e6f, 1e6f, 1e6f, 0.f};
+        if (q < g.nq && lane < HP) {
+            float sx = 1e6f, sy = 1e6f, sz = 1e6f;                   // shadow support point (kpconv_blocks.py:309)
+            if (idx < ns) {
+                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
+                n.f = g.flag[idx];
+            }
+            n.rx = sx - g.q_xyz[3 * (size_t)q]; n.ry = sy - g.q_xyz[3 * (size_t)q + 1]; n.rz = sz - g.q_xyz[3 * (size_t)q + 2];
+        }
+        return n;
+    };
+    int idx_cur = load_idx(qbase);
+    Nb nb_cur = load_nb(qbase, idx_cur);
+    int idx_nxt = load_idx(qbase + 1);
+#pragma unroll 1
     for (int qq = 0; qq < MG_QPW; qq++) {
         const int q = qbase + qq;
         if (q >= g.nq) return;          // wave-uniform
         // ---- neighbours of this query: lanes = h
         __builtin_amdgcn_wave_barrier();
         if (lane < HP) {
-            int idx = ns;
-            float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f;
-            if (lane < H) idx = g.nbr[(size_t)q * H + lane];
-            float sx = 1e6f, sy = 1e6f, sz = 1e6f;                   // shadow support point (kpconv_blocks.py:309)
-            if (idx < ns) {
-                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
-                f = g.flag[idx];
-            }
-            rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
-            rel_s[3 * lane] = rx; rel_s[3 * lane + 1] = ry; rel_s[3 * lane + 2] = rz;
-            idx_s[lane] = idx; flg_s[lane] = f;
+            rel_s[3 * lane] = nb_cur.rx; rel_s[3 * lane + 1] = nb_cur.ry; rel_s[3 * lane + 2] = nb_cur.rz;
+            idx_s[lane] = idx_cur; flg_s[lane] = nb_cur.f;
         }
         __builtin_amdgcn_wave_barrier();
         // ---- influences of kernel point k for neighbours h = 4 j + hh   (the A operands)
@@ -245,6 +258,8 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
         const float2* st = nullptr;
         if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
         float* wf_q = g.wf + (size_t)q * g.KP * Cin;
+        Nb nb_nxt{1e6f, 1e6f, 1e6f, 0.f};
+        int idx_nn = ns;
         // ---- channel passes of up to 64 channels
         for (int c0 = 0; c0 < Cin; c0 += 16 * MG_CB) {
             float xv[J][MG_CB];
@@ -253,8 +268,13 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
 #pragma unroll
                 for (int cb = 0; cb < MG_CB; cb++) {
                     const int c = c0 + cb * 16 + k;
-                    xv[j][cb] = (nidx[j] < ns && c < Cin) ? g.x[(size_t)nidx[j] * Cin + c] : 0.f;   // zero shadow row (:388)
+                    // 32-bit element offsets (host guarantees ns * Cin < 2^30): one address VGPR per gather, not two
+                    xv[j][cb] = (nidx[j] < ns && c < Cin) ? g.x[(unsigned)nidx[j] * (unsigned)Cin + (unsigned)c] : 0.f;   // zero shadow row (:388)
                 }
+            if (c0 == 0 && qq + 1 < MG_QPW) {   // prefetch for the next queries, behind this query's feature gathers
+                nb_nxt = load_nb(q + 1, idx_nxt);
+                idx_nn = load_idx(q + 2);
+            }
             if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock
 #pragma unroll
                 for (int cb = 0; cb < MG_CB; cb++) {
@@ -287,6 +307,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
                 }
             }
         }
+        idx_cur = idx_nxt; nb_cur = nb_nxt; idx_nxt = idx_nn;
     }
 }
 
@@ -403,7 +424,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }
-    if (Cin >= 16 && H <= 64) {   // matrix-core path
+    if (Cin >= 16 && H <= 64 && (long long)ns * Cin < (1LL << 30)) {   // matrix-core path
         const int grid_m = rg_cdiv(nq, GATHER_WAVES * MG_QPW);
         const int cb = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
