@@ -191,41 +191,46 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
     __shared__ float flg_sh[GATHER_WAVES][HP];
     const int wave = threadIdx.x >> 6, lane = rg_lane();
     const int k = lane & 15, hh = lane >> 4;
-    const int H = g.H, Cin = g.Cin, ns = g.ns;
+    const int H = g.H, Cin = g.Cin, ns = g.ns, nq = g.nq;
     float* rel_s = rel_sh[wave];
     int* idx_s = idx_sh[wave];
     float* flg_s = flg_sh[wave];
     const bool kvalid = k < g.KP;
-    const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+    const int kc = kvalid ? k : 0;
+    const float kx = g.kp[3 * kc], ky = g.kp[3 * kc + 1], kz = g.kp[3 * kc + 2];
     const float inv_extent = 1.0f / g.extent;
 
+    // All gathers below are BRANCH FREE: out-of-range rows / shadow neighbours load from a clamped (valid) address and
+    // are replaced by a select afterwards.  Predicated loads would split the code into basic blocks, and hipcc drains
+    // every outstanding load (s_waitcnt vmcnt(0)) at such block boundaries, which serialises the prefetch.
+    const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
+    if (qbase >= nq) return;
+    const int hl = lane < H ? lane : H - 1;
+    auto load_idx = [&](int q) -> int {
+        const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + hl];
+        return (q < nq && lane < H) ? v : ns;
+    };
+    struct Nb { float rx, ry, rz, f; };
+    auto load_nb = [&](int q, int idx) -> Nb {
+        const unsigned ic = (unsigned)(idx < ns ? idx : ns - 1), qc = (unsigned)(q < nq ? q : nq - 1);
+        const float sx = g.s_xyz[3 * ic], sy = g.s_xyz[3 * ic + 1], sz = g.s_xyz[3 * ic + 2], f = g.flag[ic];
+        const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
+        const bool real = idx < ns;                                  // else: shadow support point at 1e6 (kpconv_blocks.py:309)
+        Nb n;
+        n.rx = (real ? sx : 1e6f) - qx; n.ry = (real ? sy : 1e6f) - qy; n.rz = (real ? sz : 1e6f) - qz;
+        n.f = real ? f : 0.f;
+        return n;
+    };
     // Software pipeline over the wave's queries: the index row of query q+2 and the neighbour coordinates of query q+1
     // are requested while query q is in its gather / MFMA phase, so the idx -> xyz -> features dependency chain of one
     // query overlaps the matrix work of the previous one instead of being exposed three memory latencies deep.
-    const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
-    if (qbase >= g.nq) return;
-    auto load_idx = [&](int q) -> int { return (q < g.nq && lane < H) ? g.nbr[(size_t)q * H + lane] : ns; };
-    struct Nb { float rx, ry, rz, f; };
-    auto load_nb = [&](int q, int idx) -> Nb {
-        Nb n{1e6f, 1e6f, 1e6f, 0.f};
-        if (q < g.nq && lane < HP) {
-            float sx = 1e6f, sy = 1e6f, sz = 1e6f;                   // shadow support point (kpconv_blocks.py:309)
-            if (idx < ns) {
-                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
-                n.f = g.flag[idx];
-            }
-            n.rx = sx - g.q_xyz[3 * (size_t)q]; n.ry = sy - g.q_xyz[3 * (size_t)q + 1]; n.rz = sz - g.q_xyz[3 * (size_t)q + 2];
-        }
-        return n;
-    };
     int idx_cur = load_idx(qbase);
     Nb nb_cur = load_nb(qbase, idx_cur);
     int idx_nxt = load_idx(qbase + 1);
 #pragma unroll 1
     for (int qq = 0; qq < MG_QPW; qq++) {
         const int q = qbase + qq;
-        if (q >= g.nq) return;          // wave-uniform
-        // ---- neighbours of this query: lanes = h
+        if (q >= nq) return;            // wave-uniform
         __builtin_amdgcn_wave_barrier();
         if (lane < HP) {
             rel_s[3 * lane] = nb_cur.rx; rel_s[3 * lane + 1] = nb_cur.ry; rel_s[3 * lane + 2] = nb_cur.rz;
@@ -258,34 +263,42 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
         const float2* st = nullptr;
         if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
         float* wf_q = g.wf + (size_t)q * g.KP * Cin;
-        Nb nb_nxt{1e6f, 1e6f, 1e6f, 0.f};
+        Nb nb_nxt = nb_cur;
         int idx_nn = ns;
-        // ---- channel passes of up to 64 channels
+        // ---- channel passes of up to 16 * MG_CB channels
         for (int c0 = 0; c0 < Cin; c0 += 16 * MG_CB) {
             float xv[J][MG_CB];
 #pragma unroll
-            for (int j = 0; j < J; j++)
+            for (int j = 0; j < J; j++) {
+                // 32-bit element offsets (host guarantees ns * Cin < 2^30): one address VGPR per gather, not two
+                const unsigned row = (unsigned)(nidx[j] < ns ? nidx[j] : ns - 1) * (unsigned)Cin;
 #pragma unroll
                 for (int cb = 0; cb < MG_CB; cb++) {
                     const int c = c0 + cb * 16 + k;
-                    // 32-bit element offsets (host guarantees ns * Cin < 2^30): one address VGPR per gather, not two
-                    xv[j][cb] = (nidx[j] < ns && c < Cin) ? g.x[(unsigned)nidx[j] * (unsigned)Cin + (unsigned)c] : 0.f;   // zero shadow row (:388)
+                    xv[j][cb] = g.x[row + (unsigned)(c < Cin ? c : Cin - 1)];
                 }
-            if (c0 == 0 && qq + 1 < MG_QPW) {   // prefetch for the next queries, behind this query's feature gathers
+            }
+            if (c0 == 0) {   // prefetch for the next queries, queued behind this query's feature gathers
                 nb_nxt = load_nb(q + 1, idx_nxt);
                 idx_nn = load_idx(q + 2);
             }
-            if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock
+            if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock (wave-uniform branch)
 #pragma unroll
                 for (int cb = 0; cb < MG_CB; cb++) {
                     const int c = c0 + cb * 16 + k;
-                    if (c < Cin) {
-                        const float2 ms = st[c];
+                    const float2 ms = st[c < Cin ? c : Cin - 1];
 #pragma unroll
-                        for (int j = 0; j < J; j++)
-                            if (nidx[j] < ns) { const float t = (xv[j][cb] - ms.x) * ms.y; xv[j][cb] = t > 0.f ? t : t * g.slope; }
+                    for (int j = 0; j < J; j++) {
+                        const float t = (xv[j][cb] - ms.x) * ms.y;
+                        xv[j][cb] = t > 0.f ? t : t * g.slope;
                     }
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < J; j++) {   // zero shadow row (:388) and out-of-range channels
+                const bool real = nidx[j] < ns;
+#pragma unroll
+                for (int cb = 0; cb < MG_CB; cb++) xv[j][cb] = (real && c0 + cb * 16 + k < Cin) ? xv[j][cb] : 0.f;
             }
             floatx4 acc[MG_CB];
 #pragma unroll
@@ -298,12 +311,10 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
 #pragma unroll
             for (int cb = 0; cb < MG_CB; cb++) {
                 const int c = c0 + cb * 16 + k;
-                if (c < Cin) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int kk = 4 * hh + r;
-                        if (kk < g.KP) wf_q[(size_t)kk * Cin + c] = acc[cb][r];
-                    }
+                for (int r = 0; r < 4; r++) {
+                    const int kk = 4 * hh + r;
+                    if (kk < g.KP && c < Cin) wf_q[(unsigned)kk * (unsigned)Cin + (unsigned)c] = acc[cb][r];
                 }
             }
         }
@@ -424,7 +435,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }
-    if (Cin >= 16 && H <= 64 && (long long)ns * Cin < (1LL << 30)) {   // matrix-core path
+    if (Cin >= 16 && H <= 64 && ns > 0 && (long long)ns * Cin < (1LL << 30) && (long long)nq * H < (1LL << 31)) {   // matrix-core path
         const int grid_m = rg_cdiv(nq, GATHER_WAVES * MG_QPW);
         const int cb = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
