@@ -112,41 +112,15 @@ def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
 def measure_kpconv_roofline(model, batch, reps=5):
     """Times every KPConv gather launch (k_kpconv_gather) with HIP events on the stream it is enqueued on (torch's
     current stream) during real forwards; achieved = sum of algorithmic bytes / sum of durations."""
-    from regtr_amd import ops, _lib
+    from regtr_amd import ops
     records = []
-    L = _lib.lib()
-    real_kpconv = ops.kpconv
-
-    def timed_kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None,
-                     slope=0.1):
-        nq, H = nbr.shape
-        ns, Cin = x.shape
-        KP = kernel_points.shape[0]
-        n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
-        flag = torch.empty(ns, dtype=torch.float32, device=x.device)
-        _lib.check(L.regtr_rowsum_positive(_lib.ptr(x), ns, Cin, _lib.ptr(x_stats),
-                                           _lib.ptr(s_seg_off) if x_stats is not None else None, n_seg, slope,
-                                           _lib.ptr(flag), _lib.stream()), 'rowsum')
-        wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=x.device)
-        num = torch.empty(nq, dtype=torch.float32, device=x.device)
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
-        _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_xyz), nq, _lib.ptr(s_xyz), ns, _lib.ptr(nbr), H, _lib.ptr(x), Cin,
-                                         _lib.ptr(flag), _lib.ptr(kernel_points), KP, float(extent), _lib.ptr(x_stats),
-                                         _lib.ptr(q_seg_off) if x_stats is not None else None, n_seg, slope,
-                                         _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
-        e1.record()
-        out = ops.gemm(wf, w_flat, row_div=num)
-        e2.record()
-        records.append((e0, e1, e2, nq, H, Cin, w_flat.shape[1]))
-        return out
-    ops.kpconv = timed_kpconv
+    ops.gather_records = records
     try:
         for _ in range(reps):
             model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
         torch.cuda.synchronize()
     finally:
-        ops.kpconv = real_kpconv
+        ops.gather_records = None
     t_gather = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
     t_gemm = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3
     alg = sum(kpconv_algorithmic_bytes(r[3], r[4], r[5], r[6]) for r in records)
@@ -165,31 +139,76 @@ def measure_kpconv_roofline(model, batch, reps=5):
     }
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask, capped by a cgroup CPU quota when there is one
+    (os.cpu_count() reports the machine's cores even inside a quota-limited container, and OpenMP teams larger than
+    the quota spin against each other)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()
+            if quota != 'max':
+                n = min(n, max(1, int(float(quota) / float(period))))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pick_cpu_threads():
+    """Thread count for the CPU baseline, chosen by measurement on a 2 s probe of the same kind of work (an fp32 matmul
+    plus a row gather): the fastest of {1, 2, 4, ... usable cores}."""
+    cores = usable_cores()
+    cands = sorted({c for c in (1, 2, 4, 8, 16, 32, 64) if c <= cores} | {min(cores, 64)})
+    a = torch.randn(1024, 1024); idx = torch.randint(0, 20000, (20000, 40)); x = torch.randn(20000, 32)
+    best, best_t = 1, float('inf')
+    for c in cands:
+        torch.set_num_threads(c)
+        (a @ a).sum().item(); x[idx].sum(1)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            (a @ a).sum().item(); x[idx].sum(1)
+        dt = time.perf_counter() - t0
+        if dt < best_t * 0.9:
+            best, best_t = c, dt
+    torch.set_num_threads(best)
+    return best, cores
+
+
 def cpu_baseline(cfg, pairs, max_seconds=20.0):
     """The CPU oracle port (oracle/regtr_ref.py; preprocessing through the unmodified reference C++ when oracle/_ref is
-    present) on this box's host cores, same workload, bounded sample."""
+    present) on this box's host cores, same workload, bounded sample: whole pairs are timed until `max_seconds` of CPU
+    work have been spent (at least one pair), after a warm-up on a 1/8 crop of the first pair."""
     from oracle import native, regtr_ref, seeded_weights
     from regtr_amd.kernel_points import K015_CENTER
-    torch.set_num_threads(min(os.cpu_count(), 16))   # more threads than this slow the small torch CPU ops down
+    threads, cores = pick_cpu_threads()
     sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
     use_ref = native.have_ref()
     times, stages = [], []
-    t_start = time.perf_counter()
     with torch.no_grad():
-        for i, (s, t) in enumerate(pairs):
+        s0, t0_ = pairs[0]
+        regtr_ref.regtr_forward(sd, cfg, [s0[:len(s0) // 8]], [t0_[:len(t0_) // 8]], use_ref_cpp=use_ref)   # warm-up
+        t_start = time.perf_counter()
+        for s, t in pairs:
             tm = []
             t0 = time.perf_counter()
             regtr_ref.regtr_forward(sd, cfg, [s], [t], use_ref_cpp=use_ref, timings=tm)
-            dt = time.perf_counter() - t0
-            if i > 0 or len(pairs) == 1:
-                times.append(dt); stages.append(tm[0])
-            if time.perf_counter() - t_start > max_seconds and times:
+            times.append(time.perf_counter() - t0); stages.append(tm[0])
+            if time.perf_counter() - t_start > max_seconds:
                 break
     med = float(np.median(times))
     st = np.median(np.array(stages), axis=0)
-    return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{len(times)} timed pair(s) after 1 warm-up, same synthetic ~{len(pairs[0][0])}-pt pairs, fp32 torch CPU '
-                      f'restatement; preprocessing by {"the unmodified reference C++ (oracle/_ref)" if use_ref else "the C++ oracle restatement"}; '
+    return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{len(times)} timed pair(s) (bounded to ~{max_seconds:.0f} s of CPU work) after a warm-up on a 1/8 crop, same synthetic '
+                      f'~{len(pairs[0][0])}-pt pairs, fp32 torch CPU restatement of the reference modules on {threads} threads '
+                      f'(fastest of 1..{cores} usable cores on a probe; os.cpu_count()={os.cpu_count()}); preprocessing by '
+                      f'{"the unmodified reference C++ (oracle/_ref)" if use_ref else "the C++ oracle restatement"}; '
                       f'median s/pair {med:.2f} = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'}
 
 

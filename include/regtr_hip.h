@@ -76,8 +76,12 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
 int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
                           float* flag, void* stream);
 
+/* 1 when regtr_kpconv_gather derives the positivity flags from the feature rows it gathers anyway (Cin == 1 or a
+ * multiple of 32 with H <= 64, 16-byte aligned x / wf / x_stats): `flag` may then be NULL and regtr_rowsum_positive skipped. */
+int regtr_kpconv_gather_computes_flag(int Cin, int H);
+
 /* wf [nq, KP*Cin] (kernel point major, channel minor), num [nq] = max(1, #positive neighbours).  nbr [nq,H] int32,
- * x [ns,Cin], flag [ns], kernel_points [KP,3], KP <= 16.  x_stats [n_seg,Cin,2] + q_seg_off [n_seg+1] (optional): the
+ * x [ns,Cin], flag [ns] (or NULL, see above), kernel_points [KP,3], KP <= 16.  x_stats [n_seg,Cin,2] + q_seg_off [n_seg+1] (optional): the
  * gathered features are LeakyReLU_slope(InstanceNorm(x)) computed on the fly (cloud of a neighbour = cloud of its query). */
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
                         int Cin, const float* flag, const float* kernel_points, int KP, float extent,

@@ -10,6 +10,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libregtr_hip.so')
+if os.environ.get('REGTR_VARIANT'):      # development only: A/B kernel experiments (regtr_amd/build.py)
+    LIB_PATH = os.path.join(_HERE, f"libregtr_hip.{os.environ['REGTR_VARIANT']}.so")
 
 _c = ctypes
 _P = _c.c_void_p
@@ -25,6 +27,7 @@ SIGNATURES = {
     'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
     'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
+    'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
     'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),

@@ -7,11 +7,17 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libregtr_hip.so')
+# development only: REGTR_VARIANT=name REGTR_VARIANT_FLAGS='-DX=1' builds libregtr_hip.name.so for A/B kernel experiments
+VARIANT = os.environ.get('REGTR_VARIANT', '')
+VARIANT_FLAGS = os.environ.get('REGTR_VARIANT_FLAGS', '').split()
+if VARIANT:
+    LIB = os.path.join(HERE, f'libregtr_hip.{VARIANT}.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 SOURCES = ['preprocess.hip', 'kpconv.hip', 'gemm.hip', 'norm.hip', 'attention.hip', 'procrustes.hip']
 # bit-level parity of the float32 distance / voxel arithmetic with the reference's SSE2 build needs no contraction
-EXTRA = {'preprocess.hip': ['-ffp-contract=off']}
+# kpconv.hip: SLP-packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves and blocks v_add_f32_dpp fusion
+EXTRA = {'preprocess.hip': ['-ffp-contract=off'], 'kpconv.hip': ['-fno-slp-vectorize']}
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result',
           '-I' + os.path.join(os.path.dirname(HERE), 'include')]
 
@@ -24,7 +30,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    objdir = os.path.join(HERE, 'build')
+    objdir = os.path.join(HERE, 'build', VARIANT) if VARIANT else os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
 
@@ -32,7 +38,7 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace('.hip', '.o'))
         if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ['-c', s, '-o', o]
+            cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + VARIANT_FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)

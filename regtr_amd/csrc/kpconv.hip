@@ -167,42 +167,105 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Matrix-core gather.  For one query the kernel-point correlation  WF[k, c] = sum_h w[h, k] * x[n_h, c]  is a
-// [16 x H] x [H x Cin] product, so it runs on v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain over h in order):
-//   A operand  lane (k = l & 15, hh = l >> 4)  holds  w[h = 4 j + hh][k]      -- computed by that very lane from the
-//              centred neighbour offset and ITS kernel point, so influences go from the VALU straight into the MFMA
-//              with no LDS tile and no broadcast reads;
-//   B operand  lane (c = l & 15, hh = l >> 4)  holds  x[n_{4 j + hh}][c0 + c] -- one dword of a gathered row; all
-//              J x (Cin/16) gathers of a query are issued before the first MFMA, so tens of independent loads per lane
-//              are in flight and L2 / Infinity-Cache latency disappears behind them;
-//   D          lane holds WF[k = 4 hh + r][c0 + c], r = 0..3, written straight to the weighted-feature matrix.
-// The VALU only computes 10-16 influences per lane per query (hardware sqrt); the 15 x H x Cin multiply-adds run on
-// the matrix pipe at its full f32 rate while other waves' loads and influence maths overlap.
+// Matrix-core gather (Cin a multiple of 32).  For one query the kernel-point correlation
+//   WF[k, c] = sum_h w[h, k] * x[n_h, c]
+// is a [16 x H] x [H x Cin] product, so it runs on v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain over h in order):
+//   A operand  lane (k = l & 15, hh = l >> 4)  holds  w[h = 4 j + hh][k]  -- computed by that very lane from the centred
+//              neighbour offset and ITS kernel point, so influences go from the VALU straight into the MFMA with no LDS
+//              tile and no broadcast reads;
+//   B operand  lane (n = l & 15, hh)  holds  x[n_{4 j + hh}][c0 + V n + v], v < V: ONE 8- or 16-byte load per lane per
+//              neighbour group, the 16 lanes of a group reading one whole 128-B / 256-B feature row segment; component
+//              v feeds MFMA v, whose output column n therefore is channel c0 + V n + v.  All J loads of a pass are
+//              issued before the first MFMA, so tens of KB per CU are in flight and L2 / Infinity-Cache latency hides;
+//   D          lane holds WF[k = 4 hh + r][c0 + V n + v] in acc[v][r]: V consecutive channels -> one 8/16-byte store.
+// The per-support positivity flag of the normaliser (kpconv_blocks.py:409-410) is a row sum over the very channels the
+// wave has just gathered: per-lane partial sums + a 4-step DPP rotate-add over the 16 lanes of a group, so no separate
+// pass over x (and no flag gather) is needed.
 // ------------------------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int MG_QPW = 8;      // queries handled one after another by each wave
 
-template <int J, int MG_CB>    // J = ceil(H / 4) neighbour groups (H <= 4 J); MG_CB 16-channel blocks per pass
-__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(GatherArgs g)
+template <int V> struct RgVec;
+template <> struct RgVec<2> { typedef float2 type; };
+template <> struct RgVec<4> { typedef float4 type; };
+__device__ __forceinline__ float rg_comp(const float2& v, int i) { return i == 0 ? v.x : v.y; }
+__device__ __forceinline__ float rg_comp(const float4& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+__device__ __forceinline__ void rg_set(float2& v, int i, float f) { if (i == 0) v.x = f; else v.y = f; }
+__device__ __forceinline__ void rg_set(float4& v, int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else if (i == 2) v.z = f; else v.w = f; }
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends with the same, order-symmetric total)
+__device__ __forceinline__ float rg_row16_sum(float v)
 {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+typedef unsigned rg_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned rg_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned RG_OOB = 0x80000000u;      // byte offset beyond any buffer this kernel binds (all are < 2 GiB)
+
+// Raw buffer access (buffer_load/store ... offen): 32-bit byte offsets against a scalar resource -- one address VGPR per
+// access instead of a 64-bit pair plus the VALU that builds it -- and hardware range checking: an offset of RG_OOB
+// loads zeros / drops the store, which is exactly the "shadow row" (kpconv_blocks.py:388) and the k >= KP mask.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rg_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int V> __device__ __forceinline__ typename RgVec<V>::type rg_buf_load(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <> __device__ __forceinline__ float2 rg_buf_load<2>(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const rg_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <> __device__ __forceinline__ float4 rg_buf_load<4>(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const rg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, const float2& v)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(rg_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, off, 0, 0);
+}
+__device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(rg_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+}
+
+#ifndef RG_MG_WAVES_PER_EU
+#define RG_MG_WAVES_PER_EU 3
+#endif
+template <int J, int V>    // J = ceil(H / 4) neighbour groups (H <= 4 J); V floats per lane per row per pass
+__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_kpconv_gather_mfma(GatherArgs g)
+{
+    typedef typename RgVec<V>::type vec;
     constexpr int HP = 4 * J;
-    __shared__ float rel_sh[GATHER_WAVES][HP * 3];
-    __shared__ int idx_sh[GATHER_WAVES][HP];
-    __shared__ float flg_sh[GATHER_WAVES][HP];
-    const int wave = threadIdx.x >> 6, lane = rg_lane();
+    __shared__ float4 nb_sh[GATHER_WAVES][HP];        // (rel.x, rel.y, rel.z, feature-row byte offset) per neighbour
+    // readfirstlane: tells the compiler the wave index (hence q and everything derived from it) is wave-uniform, so the
+    // per-query buffer resource lives in SGPRs instead of being "waterfalled" lane by lane
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = rg_lane();
     const int k = lane & 15, hh = lane >> 4;
     const int H = g.H, Cin = g.Cin, ns = g.ns, nq = g.nq;
-    float* rel_s = rel_sh[wave];
-    int* idx_s = idx_sh[wave];
-    float* flg_s = flg_sh[wave];
+    float4* nb_s = nb_sh[wave];
     const bool kvalid = k < g.KP;
     const int kc = kvalid ? k : 0;
-    const float kx = g.kp[3 * kc], ky = g.kp[3 * kc + 1], kz = g.kp[3 * kc + 2];
+    // a lane without a kernel point (k = 15) sits infinitely far away: its influence clamps to 0 with no extra select
+    const float kx = kvalid ? g.kp[3 * kc] : 1e30f, ky = g.kp[3 * kc + 1], kz = g.kp[3 * kc + 2];
     const float inv_extent = 1.0f / g.extent;
+    const unsigned row_bytes = (unsigned)Cin * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = rg_rsrc(g.x, (unsigned)ns * row_bytes);
+    const __amdgpu_buffer_rsrc_t sxyz_rs = rg_rsrc(g.s_xyz, (unsigned)ns * 12u);
+    const unsigned lane_off = (unsigned)(V * k) * 4u;                 // this lane's channel bytes within a 16 V pass
+    unsigned st_off[4];                                               // WF store offsets of the lane's 4 kernel-point rows
+#pragma unroll
+    for (int r = 0; r < 4; r++) st_off[r] = (4 * hh + r) < g.KP ? (unsigned)(4 * hh + r) * row_bytes + lane_off : RG_OOB;
+    const unsigned wf_q_bytes = (unsigned)g.KP * row_bytes;
 
-    // All gathers below are BRANCH FREE: out-of-range rows / shadow neighbours load from a clamped (valid) address and
-    // are replaced by a select afterwards.  Predicated loads would split the code into basic blocks, and hipcc drains
-    // every outstanding load (s_waitcnt vmcnt(0)) at such block boundaries, which serialises the prefetch.
+    // All gathers are BRANCH FREE (range-checked buffer loads, clamped rows): predicated loads would split the code into
+    // basic blocks, and hipcc drains every outstanding load (s_waitcnt vmcnt(0)) at block boundaries, serialising the
+    // prefetch.
     const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
     if (qbase >= nq) return;
     const int hl = lane < H ? lane : H - 1;
@@ -210,15 +273,17 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
         const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + hl];
         return (q < nq && lane < H) ? v : ns;
     };
-    struct Nb { float rx, ry, rz, f; };
+    struct Nb { float rx, ry, rz; };
     auto load_nb = [&](int q, int idx) -> Nb {
-        const unsigned ic = (unsigned)(idx < ns ? idx : ns - 1), qc = (unsigned)(q < nq ? q : nq - 1);
-        const float sx = g.s_xyz[3 * ic], sy = g.s_xyz[3 * ic + 1], sz = g.s_xyz[3 * ic + 2], f = g.flag[ic];
-        const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
         const bool real = idx < ns;                                  // else: shadow support point at 1e6 (kpconv_blocks.py:309)
+        const unsigned so = real ? (unsigned)idx * 12u : RG_OOB;
+        const float sx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so, 0, 0));
+        const float sy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 4u, 0, 0));
+        const float sz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 8u, 0, 0));
+        const unsigned qc = (unsigned)(q < nq ? q : nq - 1);
+        const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
         Nb n;
         n.rx = (real ? sx : 1e6f) - qx; n.ry = (real ? sy : 1e6f) - qy; n.rz = (real ? sz : 1e6f) - qz;
-        n.f = real ? f : 0.f;
         return n;
     };
     // Software pipeline over the wave's queries: the index row of query q+2 and the neighbour coordinates of query q+1
@@ -233,91 +298,91 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_mfma(G
         if (q >= nq) return;            // wave-uniform
         __builtin_amdgcn_wave_barrier();
         if (lane < HP) {
-            rel_s[3 * lane] = nb_cur.rx; rel_s[3 * lane + 1] = nb_cur.ry; rel_s[3 * lane + 2] = nb_cur.rz;
-            idx_s[lane] = idx_cur; flg_s[lane] = nb_cur.f;
+            const unsigned ro = idx_cur < ns ? (unsigned)idx_cur * row_bytes : RG_OOB;
+            nb_s[lane] = make_float4(nb_cur.rx, nb_cur.ry, nb_cur.rz, __uint_as_float(ro));
         }
         __builtin_amdgcn_wave_barrier();
         // ---- influences of kernel point k for neighbours h = 4 j + hh   (the A operands)
         float w[J];
-        int nidx[J];
-        float fsum = 0.f;
+        unsigned row[J];       // byte offset of the neighbour's feature row; RG_OOB for a shadow neighbour (reads as zeros)
 #pragma unroll
         for (int j = 0; j < J; j++) {
-            const int h = 4 * j + hh;
-            const float dx = rel_s[3 * h] - kx, dy = rel_s[3 * h + 1] - ky, dz = rel_s[3 * h + 2] - kz;
+            const float4 nb = nb_s[4 * j + hh];
+            const float dx = nb.x - kx, dy = nb.y - ky, dz = nb.z - kz;
             float d2;
             {
 #pragma clang fp contract(off)
                 d2 = (dx * dx + dy * dy) + dz * dz;                                   // kpconv_blocks.py:326-329
             }
-            const float wv = 1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent;           // :368
-            w[j] = (kvalid && wv > 0.f) ? wv : 0.f;
-            nidx[j] = idx_s[h];
-            fsum += flg_s[h];
+            w[j] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);         // :368
+            row[j] = __float_as_uint(nb.w) + lane_off;
         }
-        // normaliser: every 16-lane group saw the flags of its hh; combine the four groups   (:409-411)
-        fsum += __shfl_xor(fsum, 16, RG_WAVE);
-        fsum += __shfl_xor(fsum, 32, RG_WAVE);
-        if (lane == 0) g.num[q] = fmaxf(fsum, 1.f);
-
         const float2* st = nullptr;
         if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
-        float* wf_q = g.wf + (size_t)q * g.KP * Cin;
+        const __amdgpu_buffer_rsrc_t wf_rs = rg_rsrc(g.wf + (size_t)q * g.KP * Cin, wf_q_bytes);
         Nb nb_nxt = nb_cur;
         int idx_nn = ns;
-        // ---- channel passes of up to 16 * MG_CB channels
-        for (int c0 = 0; c0 < Cin; c0 += 16 * MG_CB) {
-            float xv[J][MG_CB];
+        float rsum[J];
 #pragma unroll
-            for (int j = 0; j < J; j++) {
-                // 32-bit element offsets (host guarantees ns * Cin < 2^30): one address VGPR per gather, not two
-                const unsigned row = (unsigned)(nidx[j] < ns ? nidx[j] : ns - 1) * (unsigned)Cin;
+        for (int j = 0; j < J; j++) rsum[j] = 0.f;
+        // ---- channel passes of 16 V channels
+#pragma unroll 1
+        for (int c0 = 0; c0 < Cin; c0 += 16 * V) {
+            const unsigned c0b = (unsigned)c0 * 4u;
+            vec xv[J];
 #pragma unroll
-                for (int cb = 0; cb < MG_CB; cb++) {
-                    const int c = c0 + cb * 16 + k;
-                    xv[j][cb] = g.x[row + (unsigned)(c < Cin ? c : Cin - 1)];
-                }
-            }
+            for (int j = 0; j < J; j++) xv[j] = rg_buf_load<V>(x_rs, row[j] + c0b);
             if (c0 == 0) {   // prefetch for the next queries, queued behind this query's feature gathers
                 nb_nxt = load_nb(q + 1, idx_nxt);
                 idx_nn = load_idx(q + 2);
             }
             if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock (wave-uniform branch)
+                float2 ms[V];
 #pragma unroll
-                for (int cb = 0; cb < MG_CB; cb++) {
-                    const int c = c0 + cb * 16 + k;
-                    const float2 ms = st[c < Cin ? c : Cin - 1];
-#pragma unroll
-                    for (int j = 0; j < J; j++) {
-                        const float t = (xv[j][cb] - ms.x) * ms.y;
-                        xv[j][cb] = t > 0.f ? t : t * g.slope;
-                    }
+                for (int v = 0; v < V; v += 2) {
+                    const float4 t = *(const float4*)(st + c0 + V * k + v);
+                    ms[v] = make_float2(t.x, t.y); ms[v + 1] = make_float2(t.z, t.w);
                 }
+#pragma unroll
+                for (int j = 0; j < J; j++)
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        const float t = (rg_comp(xv[j], v) - ms[v].x) * ms[v].y;
+                        rg_set(xv[j], v, fmaxf(t, t * g.slope));          // LeakyReLU, 0 < slope < 1
+                    }
             }
+            // A shadow neighbour's row needs no zeroing for WF: its influence w is exactly 0 (it sits 1e6 away).  Its row
+            // sum is discarded below.
 #pragma unroll
-            for (int j = 0; j < J; j++) {   // zero shadow row (:388) and out-of-range channels
-                const bool real = nidx[j] < ns;
+            for (int j = 0; j < J; j++) {   // partial row sums for the normaliser (:409)
+                float s = rg_comp(xv[j], 0);
 #pragma unroll
-                for (int cb = 0; cb < MG_CB; cb++) xv[j][cb] = (real && c0 + cb * 16 + k < Cin) ? xv[j][cb] : 0.f;
+                for (int v = 1; v < V; v++) s += rg_comp(xv[j], v);
+                rsum[j] += s;
             }
-            floatx4 acc[MG_CB];
+            floatx4 acc[V];
 #pragma unroll
-            for (int cb = 0; cb < MG_CB; cb++) acc[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+            for (int v = 0; v < V; v++) acc[v] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < J; j++)
 #pragma unroll
-                for (int cb = 0; cb < MG_CB; cb++)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], xv[j][cb], acc[cb], 0, 0, 0);
+                for (int v = 0; v < V; v++)
+                    acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], rg_comp(xv[j], v), acc[v], 0, 0, 0);
 #pragma unroll
-            for (int cb = 0; cb < MG_CB; cb++) {
-                const int c = c0 + cb * 16 + k;
+            for (int r = 0; r < 4; r++) {
+                vec o;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int kk = 4 * hh + r;
-                    if (kk < g.KP && c < Cin) wf_q[(unsigned)kk * (unsigned)Cin + (unsigned)c] = acc[cb][r];
-                }
+                for (int v = 0; v < V; v++) rg_set(o, v, acc[v][r]);
+                rg_buf_store(wf_rs, st_off[r] + c0b, o);
             }
         }
+        // ---- normaliser: positive-row count over the query's real neighbours   (:409-411)
+        float cnt = 0.f;
+#pragma unroll
+        for (int j = 0; j < J; j++) cnt += (rg_row16_sum(rsum[j]) > 0.f && row[j] < RG_OOB) ? 1.f : 0.f;
+        cnt += __shfl_xor(cnt, 16, RG_WAVE);
+        cnt += __shfl_xor(cnt, 32, RG_WAVE);
+        if (lane == 0) g.num[q] = fmaxf(cnt, 1.f);
         idx_cur = idx_nxt; nb_cur = nb_nxt; idx_nxt = idx_nn;
     }
 }
@@ -344,7 +409,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
             float sx = 1e6f, sy = 1e6f, sz = 1e6f;
             if (idx < g.ns) {
                 sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
-                f = g.flag[idx]; x1 = g.x[idx];
+                x1 = g.x[idx]; f = g.flag ? g.flag[idx] : (x1 > 0.f ? 1.f : 0.f);
             }
             rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
         }
@@ -415,15 +480,19 @@ int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, cons
     return RG_OK;
 }
 
+// 1 when regtr_kpconv_gather derives the positivity flags from the rows it gathers (flag may then be NULL)
+int regtr_kpconv_gather_computes_flag(int Cin, int H) { return (Cin == 1 || (Cin % 32 == 0 && H <= 64)) ? 1 : 0; }
+
 // wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
                         int Cin, const float* flag, const float* kernel_points, int KP, float extent,
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
                         void* stream)
 {
-    if (!q_xyz || !s_xyz || !nbr || !x || !flag || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
+    if (!q_xyz || !s_xyz || !nbr || !x || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
         Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f) || (x_stats && (!q_seg_off || n_seg < 1)))
         return RG_ERR_ARG;
+    if (!flag && !regtr_kpconv_gather_computes_flag(Cin, H)) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
     GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
                  nq, ns, H, Cin, KP, n_seg, extent, slope};
@@ -435,14 +504,15 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }
-    if (Cin >= 16 && H <= 64 && ns > 0 && (long long)ns * Cin < (1LL << 30) && (long long)nq * H < (1LL << 31)) {   // matrix-core path
+    const bool aligned16 = (((uintptr_t)x | (uintptr_t)wf | (uintptr_t)x_stats) & 15) == 0;
+    if (!flag && !(aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29))) return RG_ERR_ARG;
+    if (regtr_kpconv_gather_computes_flag(Cin, H) && aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29)) {   // matrix-core path
         const int grid_m = rg_cdiv(nq, GATHER_WAVES * MG_QPW);
-        const int cb = Cin > 32 ? 4 : (Cin > 16 ? 2 : 1);
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
-#define RG_LAUNCH_MG(JJ, CC) k_kpconv_gather_mfma<JJ, CC><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g)
-        if (J == 10) { if (cb == 4) RG_LAUNCH_MG(10, 4); else if (cb == 2) RG_LAUNCH_MG(10, 2); else RG_LAUNCH_MG(10, 1); }
-        else if (J == 13) { if (cb == 4) RG_LAUNCH_MG(13, 4); else if (cb == 2) RG_LAUNCH_MG(13, 2); else RG_LAUNCH_MG(13, 1); }
-        else { if (cb == 4) RG_LAUNCH_MG(16, 4); else if (cb == 2) RG_LAUNCH_MG(16, 2); else RG_LAUNCH_MG(16, 1); }
+        const bool v4 = Cin % 64 == 0;
+#define RG_LAUNCH_MG(JJ) do { if (v4) k_kpconv_gather_mfma<JJ, 4><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); \
+                              else k_kpconv_gather_mfma<JJ, 2><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); } while (0)
+        if (J == 10) RG_LAUNCH_MG(10); else if (J == 13) RG_LAUNCH_MG(13); else RG_LAUNCH_MG(16);
 #undef RG_LAUNCH_MG
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;

@@ -108,16 +108,32 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     KP = kernel_points.shape[0]
     dev = x.device
     n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
-    flag = torch.empty(ns, dtype=torch.float32, device=dev)
-    check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), ptr(s_seg_off) if x_stats is not None else None, n_seg,
-                                  slope, ptr(flag), stream()), 'regtr_rowsum_positive')
+    flag = None
+    if not L.regtr_kpconv_gather_computes_flag(Cin, H):      # otherwise the gather derives the flags from the rows it reads
+        flag = torch.empty(ns, dtype=torch.float32, device=dev)
+        check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), ptr(s_seg_off) if x_stats is not None else None, n_seg,
+                                      slope, ptr(flag), stream()), 'regtr_rowsum_positive')
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
+    rec = gather_records
+    if rec is not None:
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
     check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, ptr(nbr), H, ptr(x), Cin, ptr(flag),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
                                 ptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
           'regtr_kpconv_gather')
-    return gemm(wf, w_flat, row_div=num)
+    if rec is not None:
+        e1.record()
+    out = gemm(wf, w_flat, row_div=num)
+    if rec is not None:
+        e2.record()
+        rec.append((e0, e1, e2, nq, H, Cin, w_flat.shape[1]))
+    return out
+
+
+# bench.py sets this to a list to time every KPConv gather launch (HIP events on the launch stream = torch's current one)
+gather_records = None
 
 
 def maxpool(x, nbr):

@@ -1,0 +1,65 @@
+"""Micro-benchmark of regtr_kpconv_gather on the real neighbour tables of the bench workload (run on the MI355X box):
+    [REGTR_VARIANT=name] python tools/gather_bench.py [--pairs 16]
+Prints per level: launch time, algorithmic GB/s (Nq*H*(4+12+4*Cin) + 12*Nq bytes per launch)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from regtr_amd import _lib, load_config, ops  # noqa: E402
+from regtr_amd.kpconv import Preprocessor  # noqa: E402
+from regtr_amd.kernel_points import load_kernels  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--pairs', type=int, default=16)
+    ap.add_argument('--reps', type=int, default=20)
+    args = ap.parse_args()
+    dev = torch.device('cuda', 0)
+    cfg = load_config(os.path.join(bench.ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
+    pairs = [bench.synth_pair(i, 20000) for i in range(args.pairs)]
+    pts = [torch.from_numpy(s).to(dev) for s, _ in pairs] + [torch.from_numpy(t).to(dev) for _, t in pairs]
+    meta = Preprocessor(cfg)(pts)
+    L = _lib.lib()
+    torch.manual_seed(0)
+    r0 = cfg.first_subsampling_dl * cfg.conv_radius
+    total = 0.0
+    for lvl, (Cin, strided) in enumerate([(32, False), (32, True), (64, False), (64, True), (128, False), (128, True), (256, False)]):
+        layer = [0, 0, 1, 1, 2, 2, 3][lvl]
+        s_pts = meta['points'][layer]
+        q_pts = meta['points'][layer + 1] if strided else s_pts
+        nbr = meta['_pools_i32'][layer] if strided else meta['_neighbors_i32'][layer]
+        seg_s, seg_q = meta['_seg_off'][layer], meta['_seg_off'][layer + 1 if strided else layer]
+        ns, nq, H = s_pts.shape[0], q_pts.shape[0], nbr.shape[1]
+        radius = r0 * 2 ** layer
+        kp = torch.tensor(load_kernels(radius, 15, dimension=3, fixed='center'), dtype=torch.float32, device=dev)
+        x = torch.randn(ns, Cin, device=dev)
+        st = ops.instnorm_stats(x, seg_s, max(meta['_lens_host'][layer]))
+        wf = torch.empty(nq, 15 * Cin, device=dev); num = torch.empty(nq, device=dev)
+
+        def run():
+            _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.ptr(nbr), H, _lib.ptr(x), Cin, None,
+                                             _lib.ptr(kp), 15, radius * 0.8, _lib.ptr(st), _lib.ptr(seg_q), seg_q.numel() - 1, 0.1,
+                                             _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.reps):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / args.reps * 1e3
+        alg = nq * H * (16 + 4 * Cin) + 12 * nq
+        total += us
+        print(f'layer {layer} {"pool" if strided else "conv"} Cin={Cin:3d} nq={nq:7d} ns={ns:7d}: {us:8.1f} us  {alg / us / 1e3:7.0f} GB/s alg '
+              f'(+{nq * 15 * Cin * 4 / us / 1e3:5.0f} GB/s WF write)  chk={float(wf.sum()):.6e} {float(num.sum()):.1f}')
+    print(f'total {total:.1f} us  variant={os.environ.get("REGTR_VARIANT", "")}')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,43 @@
+"""Summarise rocprofv3 --pmc csv output (one directory per counter pass) into a per-kernel table:
+mean counter value per dispatch.  usage: python tools/pmc_summary.py <outdir> [kernel-substring]"""
+import csv
+import glob
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r'\(anonymous namespace\)::', '', name)
+    name = re.sub(r'^void ', '', name)
+    m = re.match(r'([\w:<>, ]+?)\(', name)
+    return (m.group(1) if m else name)[:60]
+
+
+def main(out, filt=None):
+    vals = defaultdict(lambda: defaultdict(list))    # kernel -> counter -> [values]
+    for f in sorted(glob.glob(f'{out}/pmc_*/**/*counter_collection.csv', recursive=True)):
+        per_dispatch = defaultdict(float)
+        names = {}
+        for row in csv.DictReader(open(f)):
+            key = (row['Dispatch_Id'], row['Counter_Name'])
+            per_dispatch[key] += float(row['Counter_Value'])
+            names[row['Dispatch_Id']] = short(row['Kernel_Name'])
+        for (d, c), v in per_dispatch.items():
+            vals[names[d]][c].append(v)
+    counters = sorted({c for k in vals for c in vals[k]})
+    print('| kernel | dispatches | ' + ' | '.join(counters) + ' |')
+    print('|---|---|' + '---|' * len(counters))
+    for k in sorted(vals, key=lambda k: -sum(vals[k].get('SQ_BUSY_CYCLES', vals[k].get('GRBM_GUI_ACTIVE', [0])))):
+        if filt and filt not in k:
+            continue
+        n = max(len(v) for v in vals[k].values())
+        cells = []
+        for c in counters:
+            v = vals[k].get(c)
+            cells.append(f'{sum(v) / len(v):.4g}' if v else '')
+        print(f'| {k} | {n} | ' + ' | '.join(cells) + ' |')
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:3])
