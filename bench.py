@@ -16,6 +16,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')   # CPU-baseline leg only: idle OpenMP workers must not burn a CPU quota
+
 import numpy as np
 import torch
 
@@ -134,9 +136,26 @@ def measure_kpconv_roofline(model, batch, reps=5):
         'avg_launch_us': t_gather / n_launch * 1e6,
         'achieved_gather_kernel_GBs': alg_gather / t_gather / 1e9,
         'achieved_kpconv_op_GBs': alg / (t_gather + t_gemm) / 1e9,
-        'alg_bytes_per_step': alg / reps,
+        'alg_bytes_per_step': alg / reps, 'alg_gather_bytes_per_step': alg_gather / reps,
         'gather_s_per_step': t_gather / reps, 'gemm_s_per_step': t_gemm / reps,
     }
+
+
+def pmc_traffic(pairs, points, shuffle, detail):
+    """HBM bytes per KPConv-gather launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/gpu_round.sh and profiles/pmc_traffic.json) -- counters cannot be collected from inside the timed process, so
+    the figure is reported only when the committed profile was taken on this very workload; otherwise null."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if t.get('workload') != {'pairs': pairs, 'points': points, 'shuffle': bool(shuffle)}:
+        return None
+    detail['traffic_unit'] = 'HBM bytes per launch (mean over the gather launches of a forward)'
+    detail['traffic_source'] = t.get('source')
+    detail['alg_bytes_per_launch'] = detail['alg_gather_bytes_per_step'] / detail['launches_per_step']
+    return t['hbm_bytes_per_launch']
 
 
 def usable_cores():
@@ -161,22 +180,23 @@ def usable_cores():
     return n
 
 
-def pick_cpu_threads():
-    """Thread count for the CPU baseline, chosen by measurement on a 2 s probe of the same kind of work (an fp32 matmul
-    plus a row gather): the fastest of {1, 2, 4, ... usable cores}."""
+def pick_cpu_threads(run_probe):
+    """Thread count for the CPU baseline, chosen by MEASUREMENT: `run_probe()` (the real pipeline on a 1/4 crop) is timed
+    at all, 1/2, 1/4 of the usable cores and 1 thread, and the fastest wins; the descent stops as soon as fewer threads
+    are clearly slower.  (Under a cgroup CPU quota on a busy many-core host, OpenMP teams as large as the quota can be
+    far slower than smaller ones, so "all cores" is not assumed.)"""
     cores = usable_cores()
-    cands = sorted({c for c in (1, 2, 4, 8, 16, 32, 64) if c <= cores} | {min(cores, 64)})
-    a = torch.randn(1024, 1024); idx = torch.randint(0, 20000, (20000, 40)); x = torch.randn(20000, 32)
-    best, best_t = 1, float('inf')
+    cands = sorted({max(1, cores), max(1, cores // 2), max(1, cores // 4), 1}, reverse=True)
+    best, best_t = cands[0], float('inf')
     for c in cands:
         torch.set_num_threads(c)
-        (a @ a).sum().item(); x[idx].sum(1)
         t0 = time.perf_counter()
-        for _ in range(3):
-            (a @ a).sum().item(); x[idx].sum(1)
+        run_probe()
         dt = time.perf_counter() - t0
-        if dt < best_t * 0.9:
+        if dt < best_t:
             best, best_t = c, dt
+        elif dt > 1.3 * best_t:
+            break
     torch.set_num_threads(best)
     return best, cores
 
@@ -184,16 +204,18 @@ def pick_cpu_threads():
 def cpu_baseline(cfg, pairs, max_seconds=20.0):
     """The CPU oracle port (oracle/regtr_ref.py; preprocessing through the unmodified reference C++ when oracle/_ref is
     present) on this box's host cores, same workload, bounded sample: whole pairs are timed until `max_seconds` of CPU
-    work have been spent (at least one pair), after a warm-up on a 1/8 crop of the first pair."""
+    work have been spent (at least one pair), after warm-up / thread selection on crops of the first pair."""
     from oracle import native, regtr_ref, seeded_weights
     from regtr_amd.kernel_points import K015_CENTER
-    threads, cores = pick_cpu_threads()
     sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
     use_ref = native.have_ref()
     times, stages = [], []
     with torch.no_grad():
         s0, t0_ = pairs[0]
-        regtr_ref.regtr_forward(sd, cfg, [s0[:len(s0) // 8]], [t0_[:len(t0_) // 8]], use_ref_cpp=use_ref)   # warm-up
+        # rows are spatially ordered, so a prefix is a compact crop
+        crop = lambda f: regtr_ref.regtr_forward(sd, cfg, [s0[:len(s0) // f]], [t0_[:len(t0_) // f]], use_ref_cpp=use_ref)
+        crop(16)                                                                      # warm-up
+        threads, cores = pick_cpu_threads(lambda: crop(4))
         t_start = time.perf_counter()
         for s, t in pairs:
             tm = []
@@ -205,9 +227,9 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0):
     med = float(np.median(times))
     st = np.median(np.array(stages), axis=0)
     return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{len(times)} timed pair(s) (bounded to ~{max_seconds:.0f} s of CPU work) after a warm-up on a 1/8 crop, same synthetic '
+            'sample': f'{len(times)} timed pair(s) (bounded to ~{max_seconds:.0f} s of CPU work) after warm-up, same synthetic '
                       f'~{len(pairs[0][0])}-pt pairs, fp32 torch CPU restatement of the reference modules on {threads} threads '
-                      f'(fastest of 1..{cores} usable cores on a probe; os.cpu_count()={os.cpu_count()}); preprocessing by '
+                      f'(fastest of 1, 1/4, 1/2, all of the {cores} usable cores on a 1/4-crop probe; os.cpu_count()={os.cpu_count()}); preprocessing by '
                       f'{"the unmodified reference C++ (oracle/_ref)" if use_ref else "the C++ oracle restatement"}; '
                       f'median s/pair {med:.2f} = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'}
 
@@ -283,8 +305,9 @@ def main():
         }
         if not args.no_roofline:
             r = measure_kpconv_roofline(model, batch)
+            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r)
             res['roofline'] = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': None, 'detail': r}
+                               'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(4)])
         print(json.dumps(res))
