@@ -28,81 +28,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-# ----------------------------------------------------------------------------------------------------------------
-# synthetic 3DMatch-like pairs
-# ----------------------------------------------------------------------------------------------------------------
-def _morton(ijk):
-    ijk = ijk - ijk.min(0)
-    key = np.zeros(len(ijk), np.int64)
-    for b in range(16):
-        for a in range(3):
-            key |= ((ijk[:, a] >> b) & 1) << (3 * b + a)
-    return key
-
-
-def _scene_once(rng, side, voxel):
-    surf = []
-
-    def rect(o, u, v, n):
-        ab = rng.random((n, 2))
-        return o + ab[:, :1] * u + ab[:, 1:] * v
-
-    dens = 10.0 / (voxel * voxel)
-    X, Y, Z = 1.6 * side, 1.2 * side, 0.9 * side
-    surf.append(rect(np.zeros(3), np.array([X, 0, 0]), np.array([0, Y, 0]), int(X * Y * dens)))          # floor
-    surf.append(rect(np.zeros(3), np.array([X, 0, 0]), np.array([0, 0, Z]), int(X * Z * dens)))          # wall
-    surf.append(rect(np.zeros(3), np.array([0, Y, 0]), np.array([0, 0, Z]), int(Y * Z * dens)))          # wall
-    for _ in range(3):                                                                                   # furniture
-        o = np.array([rng.uniform(0.1 * X, 0.7 * X), rng.uniform(0.1 * Y, 0.7 * Y), 0.0])
-        w, d, h = rng.uniform(0.15, 0.3, 3) * side
-        surf.append(rect(o + [0, 0, h], np.array([w, 0, 0]), np.array([0, d, 0]), int(w * d * dens)))
-        surf.append(rect(o, np.array([w, 0, 0]), np.array([0, 0, h]), int(w * h * dens)))
-        surf.append(rect(o, np.array([0, d, 0]), np.array([0, 0, h]), int(d * h * dens)))
-    p = np.concatenate(surf)
-    p = p + rng.normal(scale=0.002, size=p.shape)
-    key = np.floor(p / voxel).astype(np.int64)
-    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
-    out = np.zeros((len(cnt), 3))
-    np.add.at(out, inv.ravel(), p)
-    out /= cnt[:, None]
-    out = out[np.argsort(_morton(np.floor(out / (4 * voxel)).astype(np.int64)), kind='stable')]
-    # rows are in Morton order of 10 cm blocks: real 3DMatch fragments are spatially coherent too (median |i - j| between
-    # neighbours is ~80 rows on the shipped red-kitchen clouds); --shuffle gives the adversarial random order
-    return out, X
-
-
-def synth_scene(rng, target_pts, voxel=0.025):
-    """Planes and boxes of a room corner sampled densely, then voxel-averaged at 2.5 cm like the 3DMatch fragments.
-    The room size is calibrated (deterministically, from the seed) so that the scene holds ~target_pts points."""
-    side = np.sqrt(target_pts * voxel * voxel / 7.0)
-    for _ in range(3):
-        out, X = _scene_once(rng, side, voxel)
-        if abs(len(out) - target_pts) < 0.03 * target_pts:
-            break
-        side *= np.sqrt(target_pts / len(out))
-    return out, X
-
-
-def random_se3(rng, rot_deg=45.0, trans=0.5):
-    axis = rng.standard_normal(3); axis /= np.linalg.norm(axis)
-    ang = np.deg2rad(rng.uniform(0, rot_deg))
-    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
-    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
-    t = rng.standard_normal(3); t = t / np.linalg.norm(t) * rng.uniform(0, trans)
-    return R, t
-
-
-def synth_pair(pair_id, pts_per_cloud=20000, shuffle=False):
-    rng = np.random.default_rng(1000 + pair_id)
-    scene, X = synth_scene(rng, int(pts_per_cloud / 0.72))
-    src = scene[scene[:, 0] < 0.72 * X]
-    tgt = scene[scene[:, 0] > 0.28 * X]
-    R, t = random_se3(rng)
-    tgt = tgt @ R.T + t + rng.normal(scale=0.005, size=tgt.shape)        # augment_noise 0.005 (3dmatch.yaml:7)
-    src = src + rng.normal(scale=0.005, size=src.shape)
-    if shuffle:
-        src, tgt = src[rng.permutation(len(src))], tgt[rng.permutation(len(tgt))]
-    return src.astype(np.float32), tgt.astype(np.float32)
+from regtr_amd.synthetic import synth_pair  # noqa: E402  (synthetic 3DMatch-like pairs)
 
 
 # ----------------------------------------------------------------------------------------------------------------

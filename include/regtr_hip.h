@@ -25,7 +25,7 @@
  *   regtr_gemm_f32            KPConv.forward                      models/backbone_kpconv/kpconv_blocks.py:269-414
  *   regtr_maxpool_gather      max_pool                            kpconv_blocks.py:127-143
  *   regtr_instnorm_*          BatchNormBlock (InstanceNorm1d) + LeakyReLU + residual   kpconv_blocks.py:497-519,556-561,741
- *   regtr_gemm_f32            nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
+ *   regtr_gemm_f32 / _x3      nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
  *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
  *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
  *   regtr_mha_fwd             nn.MultiheadAttention core          transformers.py:197-226
@@ -107,6 +107,23 @@ int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
                    const float* bias, const float* row_div, const float* residual, int ldr, int act,
                    const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
                    void* stream);
+
+/* The same contraction at float32 accuracy on the bf16 matrix cores (16x the f32-MFMA rate on gfx950): every float32 is
+ * split exactly into three bf16 (x = x0 + x1 + x2) and the product is evaluated as six bf16 MFMAs with f32 accumulation;
+ * the dropped cross terms are below one f32 ulp of each product.  Weights are split once:
+ *   regtr_gemm_split_weights(W, ld, N, K, transposed, planes)   W = [N,K] (nn.Linear.weight as stored; transposed = 0) or
+ *                                                               [K,N] (transposed = 1); planes: .._bytes(N, K) bytes
+ * regtr_gemm_x3 then has the contract of regtr_gemm_f32 with `planes` in place of B.  Shapes it does not take
+ * (regtr_gemm_x3_supported == 0: N not a multiple of 64, K not a multiple of 4) go to regtr_gemm_f32. */
+int regtr_gemm_x3_supported(int M, int N, int K);
+int regtr_gemm_x3_preferred(int M, int N, int K);   /* supported AND measured faster than regtr_gemm_f32 (K >= 128) */
+size_t regtr_gemm_split_weights_bytes(int N, int K);
+int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
+size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
+int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
+                  const float* bias, const float* row_div, const float* residual, int ldr, int act,
+                  const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
+                  void* stream);
 
 int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
                     float* y, float* y_plain, void* stream);

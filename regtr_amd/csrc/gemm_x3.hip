@@ -1,0 +1,366 @@
+// C[M,N] = epilogue( A[M,K] * W[K,N] )  at float32 accuracy on the CDNA4 *bf16* matrix cores.
+//
+// gfx950 runs f32-input MFMA at 1/16 of its bf16 MFMA rate (157 TF vs 2.5 PF).  A float32 value is EXACTLY the sum of
+// three bf16 values (8 significant bits each):  x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1),
+// and every bf16 x bf16 product is exact in f32.  So
+//     a * w  =  a0 w0 + (a0 w1 + a1 w0) + (a0 w2 + a1 w1 + a2 w0)  +  O(2^-24 |a w|)
+// and the GEMM is six v_mfma_f32_32x32x16_bf16 per (32 x 32 x 16) block with f32 accumulation -- float32-grade results
+// (the dropped terms are below one f32 ulp of each product) at up to 16/6 of the f32-MFMA rate.  Terms are issued
+// smallest first.  Serves the same call sites as gemm.hip (kpconv_blocks.py:401-406,557; regtr.py:145,432-436;
+// transformers.py:197-238) whenever N is a multiple of 64; thin / odd shapes stay on the exact-f32 kernel.
+//
+// Weights are split ONCE (regtr_gemm_split_weights) into three bf16 planes of W^T, Wt[p][n][k] (k contiguous, K padded
+// to 32 with zeros): a B fragment is then 8 consecutive k of one column = one 16-byte LDS read.  Activations are
+// split on the fly while they are staged into LDS (5.5 VALU ops per element, amortised over the BN columns of the tile).
+//
+// Workgroup = 4 waves (2 x 2), wave tile (32 WM) x (32 WN), BK = 32.  LDS rows are 64 B (32 bf16) with the four 16-byte
+// chunks of row r stored at chunk ^ ((r >> 2) & 3): the 16-byte fragment reads of the 32x32x16 MFMA and the 8-byte
+// staging stores are then bank-conflict free without padding, and the image stays lane-linear so the weight planes can
+// be streamed by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass; the swizzle is applied to
+// the per-lane SOURCE address).  Per k-tile: the A float4 loads and the B DMA of tile t+1 are issued, then the 48 MFMAs
+// per wave of tile t run from LDS while they are in flight (B double-buffered, A split + stored after the MFMAs);
+// two workgroups per CU interleave.  Split-K (deterministic two-pass) for small-M / deep-K shapes.
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int XBK = 32;          // k per tile
+constexpr int XROW = 64;         // bytes per LDS row: 32 bf16, chunk-swizzled
+
+typedef __attribute__((address_space(3))) void* x3_lds_ptr;
+
+struct X3Args {
+    const float* A; const uint16_t* Wt; float* C;
+    const float* bias; const float* row_div; const float* residual;
+    const float2* a_stats; const int* a_seg_off;
+    float* partial;
+    size_t plane;                // elements per weight plane = Npad * Kp
+    int M, N, K, Kp, lda, ldc, ldr, act, n_seg, k_chunk;
+    float a_slope;
+};
+
+__device__ __forceinline__ unsigned x3_pack(float a, float b)
+{
+    bf16x2 v;
+    v.x = (__bf16)a; v.y = (__bf16)b;            // v_cvt_pk_bf16_f32, round to nearest even
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// (a, b) -> three packed bf16 pairs, a = a0 + a1 + a2 exactly (likewise b)
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    p0 = x3_pack(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = x3_pack(ra, rb);
+    p2 = x3_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
+}
+
+template <int WM, int WN, bool STATS>
+__global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
+{
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AV = BM / 32;                   // float4 of A per thread per tile
+    constexpr int NQ = 3 * BN / 64;               // LDS-DMA instructions (1 KiB each) per wave per tile
+    constexpr int A_BYTES = 3 * BM * XROW, B_BYTES = 3 * BN * XROW;
+    __shared__ __align__(1024) unsigned char As[A_BYTES];
+    __shared__ __align__(1024) unsigned char Bs0[B_BYTES];     // two SEPARATE objects: the compiler can then tell that the
+    __shared__ __align__(1024) unsigned char Bs1[B_BYTES];     // DMA into one does not alias fragment reads of the other
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform (SGPR): LDS-DMA bases live in M0
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nk = (k_end - k_begin + XBK - 1) / XBK;
+
+    // ---- A staging: float4 #i of this thread = row (t / 8 + 32 i), k4 = (t % 8) * 4.  Loads are branch free (clamped
+    // address + select) so that nothing splits the loop body into blocks the compiler would drain loads at.
+    const int a_row = t >> 3, a_k4 = (t & 7) * 4;
+    const float* a_ptr[AV];
+    const float2* st_ptr[AV];
+    bool a_ok[AV];
+#pragma unroll
+    for (int i = 0; i < AV; i++) {
+        const int row = m0 + a_row + 32 * i;
+        a_ok[i] = row < g.M;
+        const int rc = a_ok[i] ? row : g.M - 1;
+        a_ptr[i] = g.A + (size_t)rc * g.lda;
+        st_ptr[i] = nullptr;
+        if (STATS) st_ptr[i] = g.a_stats + (size_t)rg_find_segment(g.a_seg_off, g.n_seg, rc) * g.K;
+    }
+    const unsigned a_st_off = (unsigned)a_row * XROW + ((((unsigned)a_k4 >> 3) ^ (((unsigned)a_row >> 2) & 3u)) * 16u) + ((unsigned)t & 1u) * 8u;
+    // load_a only ISSUES loads (raw values, nothing consumed): with loads and DMA in flight hipcc waits vmcnt(0) at the
+    // first use of any load result, so every use (guards, InstanceNorm fold, bf16 split) is deferred to store_a, which
+    // runs after the MFMAs of the current tile.
+    float4 ra[AV], rs01[STATS ? AV : 1], rs23[STATS ? AV : 1];
+    bool ra_kin = false;
+    auto load_a = [&](int k0) {
+        const int k = k0 + a_k4;
+        ra_kin = k < k_end;
+        const int kc = ra_kin ? k : 0;
+#pragma unroll
+        for (int i = 0; i < AV; i++) {
+            ra[i] = *(const float4*)(a_ptr[i] + kc);
+            if (STATS) {
+                rs01[i] = *(const float4*)(st_ptr[i] + kc);
+                rs23[i] = *(const float4*)(st_ptr[i] + kc + 2);
+            }
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; i++) {
+            float4 v = ra[i];
+            if (STATS) {
+                float u;
+                u = (v.x - rs01[i].x) * rs01[i].y; v.x = fmaxf(u, u * g.a_slope);
+                u = (v.y - rs01[i].z) * rs01[i].w; v.y = fmaxf(u, u * g.a_slope);
+                u = (v.z - rs23[i].x) * rs23[i].y; v.z = fmaxf(u, u * g.a_slope);
+                u = (v.w - rs23[i].z) * rs23[i].w; v.w = fmaxf(u, u * g.a_slope);
+            }
+            const bool ok = a_ok[i] && ra_kin;
+            v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            unsigned p0a, p1a, p2a, p0b, p1b, p2b;
+            x3_split2(v.x, v.y, p0a, p1a, p2a);
+            x3_split2(v.z, v.w, p0b, p1b, p2b);
+            unsigned char* dst = As + a_st_off + i * 32 * XROW;
+            *(uint2*)(dst) = make_uint2(p0a, p0b);
+            *(uint2*)(dst + BM * XROW) = make_uint2(p1a, p1b);
+            *(uint2*)(dst + 2 * BM * XROW) = make_uint2(p2a, p2b);
+        }
+    };
+    // ---- B streaming: DMA q of this wave fills LDS bytes [(wave NQ + q) 1024, +1024) of the buffer; lane i is slot
+    // s = (wave NQ + q) 64 + i = ((p BN + n) 4 + pc), holding logical chunk pc ^ ((n >> 2) & 3) of column n, plane p
+    const uint16_t* b_src[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int sidx = (wave * NQ + q) * 64 + lane;
+        const int p = sidx / (BN * 4), r = sidx % (BN * 4), n = r >> 2, kc = (r & 3) ^ ((n >> 2) & 3);
+        b_src[q] = g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + kc * 8;
+    }
+    auto dma_b = [&](int k0, unsigned char* Bb) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[q] + k0), (x3_lds_ptr)(Bb + (wave * NQ + q) * 1024), 16, 0, 0);
+    };
+
+    floatx16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // fragment byte offset of this lane within a 32-row block: row l31, logical chunk (2 ks + hi)
+    unsigned f_off[XBK / 16];
+#pragma unroll
+    for (int ks = 0; ks < XBK / 16; ks++) f_off[ks] = (unsigned)l31 * XROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
+
+    auto compute = [&](const unsigned char* Bb) {
+#pragma unroll
+        for (int ks = 0; ks < XBK / 16; ks++) {
+            bf16x8 fa[WM][3], fb[WN][3];
+#pragma unroll
+            for (int i = 0; i < WM; i++)
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+                    fa[i][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + (p * BM + (wm * WM + i) * 32) * XROW + f_off[ks]));
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int p = 0; p < 3; p++)
+                    fb[j][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + (p * BN + (wn * WN + j) * 32) * XROW + f_off[ks]));
+            // six terms, smallest first; the (i, j) loops sit inside so consecutive MFMAs hit different accumulators
+#define X3_TERM(PA, PB)                                                                                             \
+            _Pragma("unroll") for (int i = 0; i < WM; i++)                                                           \
+                _Pragma("unroll") for (int j = 0; j < WN; j++)                                                       \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+            X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) X3_TERM(1, 0) X3_TERM(0, 1) X3_TERM(0, 0)
+#undef X3_TERM
+        }
+    };
+
+    load_a(k_begin);
+    dma_b(k_begin, Bs0);
+    store_a();
+    __syncthreads();                               // (carries the vmcnt(0) that lands the DMA)
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even tile: MFMAs from Bs0 while tile kt+1 streams into Bs1 / registers
+        bool more = kt + 1 < nk;                   // wave-uniform
+        if (more) {
+            load_a(k_begin + (kt + 1) * XBK);
+            dma_b(k_begin + (kt + 1) * XBK, Bs1);
+        }
+        compute(Bs0);
+        __syncthreads();                           // every wave is done reading As
+        if (!more) break;
+        store_a();
+        __syncthreads();                           // As (and the DMA'd B buffer) visible
+        // odd tile: MFMAs from Bs1 while tile kt+2 streams into Bs0 / registers
+        more = kt + 2 < nk;
+        if (more) {
+            load_a(k_begin + (kt + 2) * XBK);
+            dma_b(k_begin + (kt + 2) * XBK, Bs0);
+        }
+        compute(Bs1);
+        __syncthreads();
+        if (!more) break;
+        store_a();
+        __syncthreads();
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+#pragma unroll
+    for (int i = 0; i < WM; i++)
+#pragma unroll
+        for (int j = 0; j < WN; j++) {
+            const int col = n0 + (wn * WN + j) * 32 + l31;
+            const int rbase = m0 + (wm * WM + i) * 32 + 4 * hi;
+            if (g.partial) {   // split-K: raw accumulators, epilogue happens in k_x3_splitk_reduce
+                float* P = g.partial + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < g.M) P[(size_t)row * g.N + col] = acc[i][j][r];
+                }
+                continue;
+            }
+            const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row >= g.M) continue;
+                float v = acc[i][j][r];
+                if (g.row_div) v = v / g.row_div[row];
+                v += bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                g.C[(size_t)row * g.ldc + col] = v;
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)g.M * g.N) return;
+    const int row = (int)(e / g.N), col = (int)(e % g.N);
+    float v = 0.f;
+    for (int s = 0; s < S; s++) v += g.partial[(size_t)s * g.M * g.N + e];   // fixed order: deterministic
+    if (g.row_div) v = v / g.row_div[row];
+    if (g.bias) v += g.bias[col];
+    if (g.act == 1) v = fmaxf(v, 0.f);
+    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+    g.C[(size_t)row * g.ldc + col] = v;
+}
+
+// W (rows x cols, leading dimension ld) -> Wt[p][n][k]: n = row (transposed == 0: W is [N, K], an nn.Linear weight) or
+// n = col (transposed == 1: W is [K, N]).  Padding (k >= K, n >= N) is zero.
+__global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ W, int ld, int N, int K, int transposed,
+                                                       int Npad, int Kp, uint16_t* __restrict__ Wt)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)Npad * Kp) return;
+    const int n = (int)(e / Kp), k = (int)(e % Kp);
+    float w = 0.f;
+    if (n < N && k < K) w = transposed ? W[(size_t)k * ld + n] : W[(size_t)n * ld + k];
+    unsigned p0, p1, p2;
+    x3_split2(w, 0.f, p0, p1, p2);
+    const size_t plane = (size_t)Npad * Kp;
+    Wt[e] = (uint16_t)(p0 & 0xffffu); Wt[plane + e] = (uint16_t)(p1 & 0xffffu); Wt[2 * plane + e] = (uint16_t)(p2 & 0xffffu);
+}
+
+struct X3Plan { int wm, wn, splits, k_chunk; };
+
+// tile shape and K split for a problem (host policy)
+X3Plan x3_plan(int M, int N, int K)
+{
+    X3Plan p{1, 1, 1, K};
+    auto tiles = [&](int wm, int wn) { return (long long)rg_cdiv(M, 64 * wm) * (N / (64 * wn)); };
+    if (N % 128 == 0 && tiles(2, 2) >= 448) { p.wm = 2; p.wn = 2; }
+    else if (tiles(2, 1) >= 448) { p.wm = 2; p.wn = 1; }
+    const long long tl = tiles(p.wm, p.wn);
+    if (tl < 384 && K >= 512) {
+        int s = (int)((768 + tl - 1) / tl);
+        const int max_by_k = K / 256;          // keep >= 256 of K per split
+        if (s > max_by_k) s = max_by_k;
+        if (s > 8) s = 8;
+        if (s >= 2) {
+            p.k_chunk = rg_cdiv(rg_cdiv(K, s), XBK) * XBK;
+            p.splits = rg_cdiv(K, p.k_chunk);
+        }
+    }
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when regtr_gemm_x3 accepts the shape (otherwise use regtr_gemm_f32)
+int regtr_gemm_x3_supported(int M, int N, int K) { return (N >= 64 && N % 64 == 0 && K >= 16 && K % 4 == 0 && M >= 0) ? 1 : 0; }
+
+// 1 when the split kernel is also the FASTER choice (measured on MI355X, tools/microbench.py): with fewer than four
+// k-tiles the activation split and the un-overlapped first tile outweigh the 16/6 MFMA-rate advantage
+int regtr_gemm_x3_preferred(int M, int N, int K) { return (regtr_gemm_x3_supported(M, N, K) && K >= 128) ? 1 : 0; }
+
+size_t regtr_gemm_split_weights_bytes(int N, int K)
+{
+    const size_t Npad = (size_t)rg_cdiv(N, 128) * 128, Kp = (size_t)rg_cdiv(K, XBK) * XBK;
+    return 3 * Npad * Kp * sizeof(uint16_t);
+}
+
+// W: float32 weights, [N, K] row-major (transposed = 0, an nn.Linear weight as stored) or [K, N] (transposed = 1, e.g. a
+// KPConv weight viewed as [15 Cin, Cout]).  planes: regtr_gemm_split_weights_bytes(N, K) bytes.
+int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream)
+{
+    if (!W || !planes || N < 1 || K < 1 || ld < (transposed ? N : K)) return RG_ERR_ARG;
+    const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
+    k_split_weights<<<rg_cdiv((long long)Npad * Kp, 256), 256, 0, (hipStream_t)stream>>>(W, ld, N, K, transposed, Npad, Kp,
+                                                                                         (uint16_t*)planes);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+size_t regtr_gemm_x3_ws_bytes(int M, int N, int K)
+{
+    if (!regtr_gemm_x3_supported(M, N, K)) return 0;
+    const X3Plan p = x3_plan(M, N, K);
+    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+// Same contract as regtr_gemm_f32 with B given as the planes written by regtr_gemm_split_weights(W, .., N, K, ..).
+int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
+                  const float* bias, const float* row_div, const float* residual, int ldr, int act,
+                  const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
+                  void* stream)
+{
+    if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
+    if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
+    if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
+    if (M == 0) return RG_OK;
+    const X3Plan p = x3_plan(M, N, K);
+    if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
+    const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
+    X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
+             p.splits > 1 ? (float*)ws : nullptr, (size_t)Npad * Kp, M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, a_slope};
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(rg_cdiv(M, 64 * p.wm), N / (64 * p.wn), p.splits);
+#define X3_LAUNCH(WM_, WN_) do { if (a_stats) k_gemm_x3<WM_, WN_, true><<<grid, 256, 0, st>>>(g); \
+                                else k_gemm_x3<WM_, WN_, false><<<grid, 256, 0, st>>>(g); } while (0)
+    if (p.wm == 2 && p.wn == 2) X3_LAUNCH(2, 2);
+    else if (p.wm == 2) X3_LAUNCH(2, 1);
+    else X3_LAUNCH(1, 1);
+#undef X3_LAUNCH
+    if (p.splits > 1) k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Batched, streamed inference harness: what test.py / demo.py run around `RegTR.forward`.
+
+Replaces, for inference only, the reference's Trainer.test loop (/root/reference/src/trainer.py:177-211) and
+GenericRegModel.test_step / _save_3DMatch_log (models/generic_reg_model.py:130-158, 260-281):
+  * B pairs per forward instead of one (conf test_batch_size: 1), next batch loaded by a worker thread into pinned
+    memory and copied to the GPU on a side stream while the current batch computes;
+  * no compute_loss, no tensorboard, no per-pair host synchronisation: poses stay on the device until the end of the set;
+  * pairs sharded over ranks (one process per GPU) with a single RCCL gather of the poses; rank 0 writes the logs;
+  * `est.log` blocks / `pred_transforms.npy` in the reference's exact formats, so the reference's own evaluation scripts
+    (benchmark_predator / RPMNet eval) read them unchanged.
+"""
+import os
+import pickle
+import queue
+import threading
+import time
+
+import numpy as np
+import torch
+
+from .distributed import gather_poses, shard_pairs
+
+
+# ------------------------------------------------------------------------------------------------------ point cloud files
+def read_ply_xyz(fname):
+    """Minimal PLY reader (ascii / binary_little_endian, vertex x y z as float or double) -- stands in for
+    open3d.io.read_point_cloud in demo.py:145-147."""
+    with open(fname, 'rb') as f:
+        if f.readline().strip() != b'ply':
+            raise AssertionError(f'{fname}: not a PLY file')
+        fmt, n_vert, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise AssertionError(f'{fname}: truncated PLY header')
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == b'format':
+                fmt = tok[1].decode()
+            elif tok[0] == b'element':
+                in_vertex = tok[1] == b'vertex'
+                if in_vertex:
+                    n_vert = int(tok[2])
+            elif tok[0] == b'property' and in_vertex:
+                props.append((tok[1].decode(), tok[2].decode()))
+            elif tok[0] == b'end_header':
+                break
+        names = [p[1] for p in props]
+        if not all(a in names for a in 'xyz'):
+            raise AssertionError(f'{fname}: vertex element has no x/y/z')
+        if fmt == 'ascii':
+            rows = np.loadtxt(f, max_rows=n_vert, ndmin=2)
+            return rows[:, [names.index(a) for a in 'xyz']].astype(np.float64)
+        if fmt != 'binary_little_endian':
+            raise AssertionError(f'{fname}: unsupported PLY format {fmt}')
+        np_t = {'float': '<f4', 'float32': '<f4', 'double': '<f8', 'float64': '<f8', 'uchar': 'u1', 'uint8': 'u1', 'char': 'i1',
+                'int8': 'i1', 'short': '<i2', 'int16': '<i2', 'ushort': '<u2', 'uint16': '<u2', 'int': '<i4', 'int32': '<i4',
+                'uint': '<u4', 'uint32': '<u4'}
+        dt = np.dtype([(n, np_t[t]) for t, n in props])
+        data = np.frombuffer(f.read(n_vert * dt.itemsize), dtype=dt, count=n_vert)
+        return np.stack([data['x'], data['y'], data['z']], 1).astype(np.float64)
+
+
+def load_point_cloud(fname):
+    """demo.py:142-153: .pth (torch-saved array), .ply, .bin (KITTI float32 x y z r); returns (N, 3)."""
+    if fname.endswith('.pth'):
+        data = torch.load(fname, weights_only=False)
+        data = data.numpy() if isinstance(data, torch.Tensor) else np.asarray(data)
+    elif fname.endswith('.ply'):
+        data = read_ply_xyz(fname)
+    elif fname.endswith('.bin'):
+        data = np.fromfile(fname, dtype=np.float32).reshape(-1, 4)
+    else:
+        raise AssertionError('Cannot recognize point cloud format')
+    return data[:, :3]
+
+
+# ------------------------------------------------------------------------------------------------------ pair sources
+class ThreeDMatchPairs:
+    """The 3DMatch / 3DLoMatch test pairs (data_loaders/threedmatch.py:20-101, test phase): an info pickle with keys
+    rot (3,3), trans (3,1), src, tgt (paths relative to `root`), overlap."""
+
+    def __init__(self, info_fname, root):
+        with open(info_fname, 'rb') as fid:
+            self.infos = pickle.load(fid)
+        self.root = root
+
+    def __len__(self):
+        return len(self.infos['rot'])
+
+    def __getitem__(self, i):
+        src_path, tgt_path = self.infos['src'][i], self.infos['tgt'][i]
+        pose = np.concatenate([self.infos['rot'][i], self.infos['trans'][i].reshape(3, 1)], 1).astype(np.float32)
+        return {'src_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, src_path)), dtype=np.float32),
+                'tgt_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, tgt_path)), dtype=np.float32),
+                'pose': pose, 'idx': i, 'src_path': src_path, 'tgt_path': tgt_path}
+
+
+class SyntheticPairs:
+    """N deterministic synthetic 3DMatch-sized pairs (regtr_amd/synthetic.py) laid out like the 3DMatch test set
+    (scene folders, cloud_bin_<k>.pth names) so that the est.log writer is exercised unchanged."""
+
+    def __init__(self, n, points=20000, pairs_per_scene=64):
+        self.n, self.points, self.pps = n, points, pairs_per_scene
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from .synthetic import synth_pair
+        src, tgt, pose = synth_pair(i, self.points, return_pose=True)
+        scene, k = i // self.pps, i % self.pps
+        return {'src_xyz': src, 'tgt_xyz': tgt, 'pose': pose, 'idx': i,
+                'src_path': f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k + 1}.pth',
+                'tgt_path': f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k}.pth'}
+
+
+# ------------------------------------------------------------------------------------------------------ streaming
+class Prefetcher:
+    """Iterates `indices` of `pairs` in batches of `batch`; a worker thread loads the next batches (disk / generator,
+    pinned host buffers), the H2D copies run on a side stream, and the consumer stream waits on an event only."""
+
+    def __init__(self, pairs, indices, batch, device, depth=2):
+        self.pairs, self.indices, self.batch, self.device = pairs, list(indices), batch, device
+        self.q = queue.Queue(maxsize=depth)
+        self.copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.thread = threading.Thread(target=self._work, daemon=True)
+        self.thread.start()
+
+    def _work(self):
+        try:
+            for s in range(0, len(self.indices), self.batch):
+                items = [self.pairs[i] for i in self.indices[s:s + self.batch]]
+                out = {'items': items}
+                if self.copy_stream is not None:
+                    with torch.cuda.stream(self.copy_stream):
+                        for key in ('src_xyz', 'tgt_xyz'):
+                            out[key] = [torch.from_numpy(it[key]).pin_memory().to(self.device, non_blocking=True) for it in items]
+                        out['ready'] = torch.cuda.Event()
+                        out['ready'].record(self.copy_stream)
+                else:
+                    for key in ('src_xyz', 'tgt_xyz'):
+                        out[key] = [torch.from_numpy(it[key]) for it in items]
+                self.q.put(out)
+            self.q.put(None)
+        except BaseException as e:      # surface loader errors in the consumer
+            self.q.put(e)
+
+    def __iter__(self):
+        while True:
+            b = self.q.get()
+            if b is None:
+                return
+            if isinstance(b, BaseException):
+                raise b
+            if 'ready' in b:
+                torch.cuda.current_stream(self.device).wait_event(b['ready'])
+                for key in ('src_xyz', 'tgt_xyz'):      # the tensors were allocated on the copy stream
+                    for t in b[key]:
+                        t.record_stream(torch.cuda.current_stream(self.device))
+            yield b
+
+
+# ------------------------------------------------------------------------------------------------------ result files
+def write_est_log(log_path, benchmark, records):
+    """generic_reg_model.py:260-281: per scene `<log_path>/<benchmark>/<scene>/est.log`, one block per pair:
+    "{tgt_idx}\\t{src_idx}\\t-1" then the 4x4 pose, rows tab-separated with 12 decimals."""
+    by_scene = {}
+    for rec in records:
+        scene = rec['src_path'].split(os.path.sep)[1]
+        by_scene.setdefault(scene, []).append(rec)
+    for scene, recs in by_scene.items():
+        folder = os.path.join(log_path, benchmark, scene)
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, 'est.log'), 'a') as fid:
+            for rec in recs:
+                src_idx = int(os.path.basename(rec['src_path']).split('_')[-1].replace('.pth', ''))
+                tgt_idx = int(os.path.basename(rec['tgt_path']).split('_')[-1].replace('.pth', ''))
+                pose = np.asarray(rec['pose'], dtype=np.float64)
+                if pose.shape[0] == 3:
+                    pose = np.concatenate([pose, [[0., 0., 0., 1.]]], axis=0)
+                fid.write('{}\t{}\t{}\n'.format(tgt_idx, src_idx, -1))
+                for i in range(4):
+                    fid.write('\t'.join(map('{0:.12f}'.format, pose[i])) + '\n')
+
+
+def pose_errors(pred, gt):
+    """Rotation error (deg) and translation error of (n, 3, 4) predictions against ground truth
+    (utils/se3_torch.py se3_compare / generic_reg_model.py:198-210)."""
+    pred, gt = np.asarray(pred, np.float64), np.asarray(gt, np.float64)
+    Rd = np.einsum('nij,nkj->nik', pred[:, :, :3], gt[:, :, :3])
+    tr = np.clip((np.trace(Rd, axis1=1, axis2=2) - 1) / 2, -1, 1)
+    return np.degrees(np.arccos(tr)), np.linalg.norm(pred[:, :, 3] - gt[:, :, 3], axis=1)
+
+
+# ------------------------------------------------------------------------------------------------------ the test loop
+def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
+    """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  Returns, on every rank,
+    (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids, timing dict)."""
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    n = len(pairs) if max_pairs is None else min(len(pairs), max_pairs)
+    mine = shard_pairs(n, rank, world)
+    model.eval()
+    poses, ids = [], []
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for b in Prefetcher(pairs, mine, batch, device):
+            out = model({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
+            poses.append(out['pose'][-1])                         # (B, 3, 4), stays on the device
+            ids.extend(it['idx'] for it in b['items'])
+    pose_t = torch.cat(poses).reshape(-1, 12) if poses else torch.zeros((0, 12), dtype=torch.float32, device=device)
+    id_t = torch.tensor(ids, dtype=torch.int32, device=device)
+    all_poses, all_ids = gather_poses(pose_t, id_t)
+    if device.type == 'cuda':
+        torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    if logger and rank == 0:
+        logger.info(f'{n} pairs on {world} GPU(s) in {elapsed:.2f} s = {n / elapsed:.1f} pairs/s (incl. loading)')
+    return all_poses.reshape(-1, 3, 4).cpu().numpy(), all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world}

@@ -124,9 +124,11 @@ class KPConv(nn.Module):
         nn.init.kaiming_uniform_(self.weights, a=5 ** 0.5)                      # kpconv_blocks.py:248-249
         kp = load_kernels(radius, kernel_size, dimension=p_dim, fixed=fixed_kernel_points)
         self.kernel_points = nn.Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)   # :266
+        self._cache = {}
 
     def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None):
-        w = self.weights.detach().view(self.K * self.in_channels, self.out_channels)
+        w = _prepared(self._cache, 'w', self.weights,
+                      lambda p: ops.SplitWeight(p.view(self.K * self.in_channels, self.out_channels), 'kn'))
         return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent,
                           x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off)
 
@@ -144,7 +146,7 @@ class UnaryBlock(nn.Module):
 
     def linear(self, x, a_stats=None, a_seg_off=None):
         """The Linear alone; its InstanceNorm (+LeakyReLU) is folded into whichever kernel consumes the result."""
-        wt = _prepared(self._cache, 'w', self.mlp.weight, lambda w: w.t().contiguous())
+        wt = _prepared(self._cache, 'w', self.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
         return ops.gemm(x, wt, a_stats=a_stats, a_seg_off=a_seg_off)
 
     def forward(self, x, seg_off, max_len):

@@ -53,24 +53,61 @@ class CellGrid:
 
 
 # ------------------------------------------------------------------------------------------------ dense
-def gemm(a, b_kn, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1):
-    """a (M,K) @ b_kn (K,N) with the fused epilogue of regtr_gemm_f32.  `a` may be a row-strided view.
+class SplitWeight:
+    """A weight matrix prepared for both dense kernels: `kn` (K, N) float32 for regtr_gemm_f32 and, when N is a multiple
+    of 64, the three bf16 planes of its exact 3-way split for regtr_gemm_x3.  Build once per parameter (cache it)."""
+
+    def __init__(self, w, layout):
+        """w: float32 CUDA tensor; layout 'nk' = (N, K) as nn.Linear stores it, 'kn' = (K, N)."""
+        L = _lib.lib()
+        w = w.detach().contiguous()
+        if layout == 'nk':
+            self.N, self.K = w.shape
+            self.kn = w.t().contiguous()
+        else:
+            self.K, self.N = w.shape
+            self.kn = w
+        self.planes = None
+        if L.regtr_gemm_x3_supported(1, self.N, self.K):
+            self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
+            check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, ptr(self.planes),
+                                             stream()), 'regtr_gemm_split_weights')
+
+
+def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1):
+    """a (M,K) @ b with the fused epilogue of regtr_gemm_f32 / regtr_gemm_x3.  b: a (K,N) float32 tensor (exact-f32 MFMA
+    kernel) or a SplitWeight (bf16x3 split kernel when the shape allows).  `a` may be a row-strided view.
     a_stats (n_seg,K,2) + a_seg_off: A is read as LeakyReLU(InstanceNorm(a)) (per-cloud stats) on the fly."""
     L = _lib.lib()
     M, K = a.shape
+    sw = b if isinstance(b, SplitWeight) else None
+    b_kn = sw.kn if sw is not None else b
     Kb, N = b_kn.shape
     assert K == Kb and a.stride(1) == 1 and b_kn.is_contiguous()
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldr = residual.stride(0) if residual is not None else 0
+    lda = a.stride(0) if M > 1 else K
+    ldc = out.stride(0) if M > 1 else N
+    n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
+    if (sw is not None and sw.planes is not None and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm
+            and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
+        nb = L.regtr_gemm_x3_ws_bytes(M, N, K)
+        ws = _ws(nb, a.device) if nb else None
+        check(L.regtr_gemm_x3(a.data_ptr(), lda, ptr(sw.planes), out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
+                              residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
+                              ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_x3')
+        return out
     nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
     ws = _ws(nb, a.device) if nb else None
-    n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
-    check(L.regtr_gemm_f32(a.data_ptr(), a.stride(0) if M > 1 else K, ptr(b_kn), N, out.data_ptr(),
-                           out.stride(0) if M > 1 else N, M, N, K, ptr(bias), ptr(row_div),
+    check(L.regtr_gemm_f32(a.data_ptr(), lda, ptr(b_kn), N, out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
                            residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
                            ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_f32')
     return out
+
+
+force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel
+force_x3_gemm = False       # tests: route every supported shape to the split kernel, also where it is not the faster one
 
 
 def layernorm(x, gamma, beta, add=None, eps=1e-5, want_plain=False, out=None):
@@ -128,7 +165,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     out = gemm(wf, w_flat, row_div=num)
     if rec is not None:
         e2.record()
-        rec.append((e0, e1, e2, nq, H, Cin, w_flat.shape[1]))
+        rec.append((e0, e1, e2, nq, H, Cin, out.shape[1]))
     return out
 
 

@@ -51,7 +51,7 @@ class CorrespondenceRegressor(nn.Module):
         """feats (L, N, D) -> corr (L, N, 3), logit (L, N)."""
         Lyr, N, D = feats.shape
         f = feats.view(Lyr * N, D)
-        wt = lambda k, lin: _prepared(self._cache, k, lin.weight, lambda w: w.t().contiguous())
+        wt = lambda k, lin: _prepared(self._cache, k, lin.weight, lambda w: ops.SplitWeight(w, 'nk'))
         h = ops.gemm(f, wt('0', self.coor_mlp[0]), bias=self.coor_mlp[0].bias.detach(), relu=True)
         h = ops.gemm(h, wt('2', self.coor_mlp[2]), bias=self.coor_mlp[2].bias.detach(), relu=True)
         corr = ops.gemm(h, wt('4', self.coor_mlp[4]), bias=self.coor_mlp[4].bias.detach())
@@ -124,7 +124,7 @@ class RegTR(nn.Module):
         if ev: ev[2].record()
 
         # ---- projection, positional embedding, cross-encoder on packed tokens (regtr.py:145-166)
-        wt = _prepared(self._cache, 'feat_proj', self.feat_proj.weight, lambda w: w.t().contiguous())
+        wt = _prepared(self._cache, 'feat_proj', self.feat_proj.weight, lambda w: ops.SplitWeight(w, 'nk'))
         both_feats_un = ops.gemm(feats_un, wt, bias=self.feat_proj.bias.detach())
         xyz_c = kpconv_meta['points'][-1]
         seg_c = kpconv_meta['_seg_off'][-1]

@@ -39,25 +39,28 @@ class TransformerCrossEncoderLayer(nn.Module):
         self.sa_val_has_pos_emb, self.ca_val_has_pos_emb = sa_val_has_pos_emb, ca_val_has_pos_emb
         self._cache = {}
 
-    def _wt(self, name, param):
-        return _prepared(self._cache, name, param, lambda w: w.t().contiguous())
+    def _wt(self, name, param, rows=None):
+        """The weight (optionally a row block of it: in_proj packs q, k, v) prepared once for the dense kernels."""
+        key = name if rows is None else (name, rows)
+        return _prepared(self._cache, key, param, lambda w: ops.SplitWeight(w if rows is None else w[rows[0]:rows[1]], 'nk'))
 
     def _attention(self, attn, tag, x, norm, pe, val_has_pe, seg_off, kv_of, max_len):
         """x + out_proj( MHA(q = k = LN(x) + pe, v = LN(x) [+ pe]) ) for every token (transformers.py:194-229)."""
         D = self.d_model
-        w_in = self._wt(tag + '_in', attn.in_proj_weight)                      # (D, 3D)
         b_in = attn.in_proj_bias.detach()
         if pe is None:
             x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), eps=norm.eps)
-            qkv = ops.gemm(x2p, w_in, bias=b_in)
+            qkv = ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
         elif val_has_pe:
             x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps)
-            qkv = ops.gemm(x2p, w_in, bias=b_in)
+            qkv = ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
         else:
             x2p, x2 = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps, want_plain=True)
             qkv = torch.empty((x.shape[0], 3 * D), dtype=torch.float32, device=x.device)
-            ops.gemm(x2p, w_in[:, :2 * D].contiguous(), bias=b_in[:2 * D].contiguous(), out=qkv[:, :2 * D])
-            ops.gemm(x2, w_in[:, 2 * D:].contiguous(), bias=b_in[2 * D:].contiguous(), out=qkv[:, 2 * D:])
+            b_qk = _prepared(self._cache, tag + '_bqk', attn.in_proj_bias, lambda b: b[:2 * D].contiguous())
+            b_v = _prepared(self._cache, tag + '_bv', attn.in_proj_bias, lambda b: b[2 * D:].contiguous())
+            ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
+            ops.gemm(x2, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
         att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
         return ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
 

@@ -1,0 +1,154 @@
+"""Evaluation entry point with the reference's command line (/root/reference/src/test.py:13-29):
+
+    python test.py --benchmark {3DMatch,3DLoMatch,ModelNet,ModelLoNet} [--config CFG] [--resume CKPT]
+                   [--logdir DIR] [--dev] [--name NAME] [--num_workers N]
+    (N GPUs: python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 test.py ...)
+
+Runs the MI355X-native RegTR inference path over the benchmark's pairs and writes `<log>/<benchmark>/<scene>/est.log`
+(3DMatch / 3DLoMatch) or `<log>/pred_transforms.npy` (ModelNet / ModelLoNet) in the reference's formats
+(models/generic_reg_model.py:194-195, 260-281), which the reference's evaluation scripts read unchanged.
+Inference only: no loss, no tensorboard.  Extra flags: --batch (pairs per forward), --data_root, --synthetic N
+(N deterministic synthetic pairs instead of the dataset files), --max_pairs.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--benchmark', type=str, help='Benchmark dataset', default='3DMatch',
+                    choices=['3DMatch', '3DLoMatch', 'ModelNet', 'ModelLoNet'])
+parser.add_argument('--config', type=str, help='Path to the config file.')
+parser.add_argument('--logdir', type=str, default='../logs', help='Directory to store logs, summaries, checkpoints.')
+parser.add_argument('--dev', action='store_true', help='If true, will ignore logdir and log to ../logdev instead')
+parser.add_argument('--name', type=str, help='Prefix to add to logging directory')
+parser.add_argument('--num_workers', type=int, default=0, help='(accepted for compatibility; loading is prefetched by a thread)')
+parser.add_argument('--resume', type=str, help='Checkpoint to resume from')
+# harness options (not in the reference)
+parser.add_argument('--batch', type=int, default=8, help='pairs per forward')
+parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.root (folder holding test/<scene>/cloud_bin_*.pth)')
+parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
+parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
+parser.add_argument('--max_pairs', type=int, default=None)
+
+
+def prepare_logger(opt, rank):
+    """cvhelpers.misc.prepare_logger: <logdir>/<yymmdd_HHMMSS>[_name] (or ../logdev with --dev), log.txt inside."""
+    if opt.dev:
+        log_path = '../logdev'
+    else:
+        stamp = time.strftime('%y%m%d_%H%M%S')
+        log_path = os.path.join(opt.logdir, stamp if not opt.name else f'{stamp}_{opt.name}')
+    logger = logging.getLogger('regtr_amd.test')
+    logger.setLevel(logging.INFO)
+    handlers = [logging.StreamHandler()]
+    if rank == 0:
+        os.makedirs(log_path, exist_ok=True)
+        handlers.append(logging.FileHandler(os.path.join(log_path, 'log.txt')))
+    for h in handlers:
+        h.setFormatter(logging.Formatter('%(asctime)s [%(levelname)s] %(message)s'))
+        logger.addHandler(h)
+    return logger, log_path
+
+
+def main():
+    opt = parser.parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    logger, opt.log_path = prepare_logger(opt, rank)
+
+    # config resolution exactly as test.py:33-52
+    if opt.config is None:
+        if opt.resume is None or not os.path.exists(opt.resume):
+            logger.error('--config needs to be supplied unless resuming from checkpoint')
+            sys.exit(-1)
+        resume_folder = opt.resume if os.path.isdir(opt.resume) else os.path.dirname(opt.resume)
+        opt.config = os.path.normpath(os.path.join(resume_folder, '../config.yaml'))
+        if os.path.exists(opt.config):
+            logger.info(f'Using config file from checkpoint directory: {opt.config}')
+        else:
+            logger.error('Config not found in resume directory')
+            sys.exit(-2)
+    elif rank == 0:
+        with open(opt.config, 'r') as in_fid, open(os.path.join(opt.log_path, 'config.yaml'), 'w') as out_fid:
+            out_fid.write(f'# Original file name: {opt.config}\n')
+            out_fid.write(in_fid.read())
+
+    from regtr_amd import RegTR, load_config
+    from regtr_amd import harness
+    cfg = load_config(opt.config)
+    if cfg.dataset == '3dmatch':
+        assert opt.benchmark in ['3DMatch', '3DLoMatch'], "Benchmark for 3dmatch dataset must be one of ['3DMatch', '3DLoMatch']"
+        cfg.benchmark = opt.benchmark
+    elif cfg.dataset == 'modelnet':
+        assert opt.benchmark in ['ModelNet', 'ModelLoNet'], "Benchmark for modelnet dataset must be one of ['ModelNet', 'ModelLoNet']"
+        cfg.partial = [0.7, 0.7] if opt.benchmark == 'ModelNet' else [0.5, 0.5]
+
+    if not torch.cuda.is_available():
+        logger.error('regtr_amd runs on an MI355X (HIP) device only; there is no CPU path')
+        sys.exit(-3)
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    # pairs
+    if opt.synthetic > 0:
+        pairs = harness.SyntheticPairs(opt.synthetic, points=20000 if cfg.dataset == '3dmatch' else 717)
+    elif cfg.dataset == '3dmatch':
+        info = opt.info or os.path.join('datasets', '3dmatch', f'test_{opt.benchmark}_info.pkl')
+        roots = [opt.data_root] if opt.data_root else ([cfg.root] if isinstance(cfg.root, str) else list(cfg.root))
+        root = next((r for r in roots if os.path.exists(os.path.join(r, 'test'))), None)
+        if root is None or not os.path.exists(info):
+            logger.error(f'Dataset not found (info {info}, roots {roots}); pass --data_root / --info or use --synthetic N')
+            sys.exit(-4)
+        pairs = harness.ThreeDMatchPairs(info, root)
+    else:
+        logger.error('ModelNet h5 loading is not part of the inference hot path here (h5py is not a dependency); use --synthetic N')
+        sys.exit(-4)
+
+    model = RegTR(cfg).to(device)
+    if opt.resume:
+        state = torch.load(opt.resume, map_location=device, weights_only=False)
+        missing = model.load_state_dict(state['state_dict'], strict=False)       # CheckPointManager.load (torch_helpers.py:222)
+        logger.info(f'Loaded checkpoint {opt.resume} (step {state.get("step", "?")}); {missing}')
+    else:
+        logger.warning('No checkpoint given. Will perform inference using random weights')
+
+    poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs)
+    if rank == 0:
+        recs, gts = [], []
+        for pose, i in zip(poses, ids):
+            meta = pairs[int(i)] if opt.synthetic > 0 else {'src_path': pairs.infos['src'][int(i)], 'tgt_path': pairs.infos['tgt'][int(i)],
+                                                            'pose': np.concatenate([pairs.infos['rot'][int(i)], pairs.infos['trans'][int(i)].reshape(3, 1)], 1)}
+            recs.append({'src_path': meta['src_path'], 'tgt_path': meta['tgt_path'], 'pose': pose})
+            gts.append(meta['pose'])
+        if cfg.dataset == '3dmatch':
+            harness.write_est_log(opt.log_path, opt.benchmark, recs)
+            logger.info(f'est.log files written under {os.path.join(opt.log_path, opt.benchmark)}')
+        else:
+            np.save(os.path.join(opt.log_path, 'pred_transforms.npy'), poses[:, None])    # (n, 1, 3, 4) like torch.stack of (B=1,3,4)
+        rot, trans = harness.pose_errors(poses, np.stack(gts))
+        ok = np.logical_and(rot < cfg.get('reg_success_thresh_rot', 10), trans < cfg.get('reg_success_thresh_trans', 0.1))
+        logger.info(f'[Metrics] rot_err_deg_final: {rot.mean():.4f}, trans_err_final: {trans.mean():.4f}, reg_success_final: {ok.mean():.4f} '
+                    f'({len(ids)} pairs, {timing["pairs"] / timing["elapsed_s"]:.1f} pairs/s on {timing["world"]} GPU(s))')
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

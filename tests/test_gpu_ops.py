@@ -53,6 +53,72 @@ def test_gemm_strided_views():
     assert out[:, 512:].abs().max() == 0
 
 
+# ------------------------------------------------------------------------------------------------ bf16x3 split GEMM
+@pytest.fixture
+def x3_forced():
+    ops = _ops()
+    ops.force_x3_gemm = True
+    yield ops
+    ops.force_x3_gemm = False
+
+
+def test_gemm_x3_identity_asymmetric(x3_forced):
+    """A = I with an asymmetric B through the split kernel: exact (every float32 here is an exact 3 x bf16 sum)."""
+    ops = x3_forced
+    n = 128
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) * 0.5 + torch.arange(n, dtype=torch.float32)[:, None] * 7
+    for layout, w in (('kn', b), ('nk', b.t().contiguous())):
+        sw = ops.SplitWeight(w.cuda(), layout)
+        assert sw.planes is not None
+        out = ops.gemm(torch.eye(n).cuda(), sw)
+        assert torch.equal(out.cpu(), b), layout
+
+
+@pytest.mark.parametrize('M,N,K,layout', [(751, 256, 256, 'nk'), (2753, 512, 128, 'nk'), (130, 1024, 3840, 'nk'),
+                                          (9381, 256, 3840, 'kn'), (40000, 64, 960, 'kn'), (1000, 128, 32, 'nk'),
+                                          (513, 64, 16, 'nk'), (300, 768, 256, 'nk'), (70000, 128, 64, 'nk'), (1, 256, 1024, 'nk')])
+def test_gemm_x3_vs_fp64(M, N, K, layout, x3_forced):
+    """The bf16x3 split kernel is float32-grade: its error against float64 is within the bound used for the exact-f32
+    MFMA kernel and within 2x of that kernel's own error."""
+    ops = x3_forced
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g)); b = torch.randn(K, N, generator=g)
+    bias = torch.randn(N, generator=g); div = torch.randint(1, 40, (M,), generator=g).float(); res = torch.randn(M, N, generator=g)
+    ref = (a.double() @ b.double())
+    sw = ops.SplitWeight((b if layout == 'kn' else b.t().contiguous()).cuda(), layout)
+    assert sw.planes is not None
+    out = ops.gemm(a.cuda(), sw).cpu()
+    out_f32 = ops.gemm(a.cuda(), b.cuda()).cpu()
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-6
+    scale = max(1.0, ref.abs().max().item() / 10)
+    err, err_f32 = (out.double() - ref).abs().max().item(), (out_f32.double() - ref).abs().max().item()
+    assert err < tol * scale, (err, err_f32)
+    assert err < 2 * err_f32 + 1e-7 * scale, (err, err_f32)
+    ref2 = torch.relu(ref / div[:, None].double() + bias.double()) + res.double()
+    out2 = ops.gemm(a.cuda(), sw, bias=bias.cuda(), row_div=div.cuda(), residual=res.cuda(), relu=True).cpu()
+    assert (out2.double() - ref2).abs().max() < tol * scale
+
+
+def test_gemm_x3_strided_and_fused_norm(x3_forced):
+    ops = x3_forced
+    g = torch.Generator().manual_seed(11)
+    big = torch.randn(300, 768, generator=g).cuda()
+    w = torch.randn(512, 256, generator=g).cuda()                     # (N, K) like nn.Linear
+    out = torch.zeros(300, 768).cuda()
+    ops.gemm(big[:, 256:512], ops.SplitWeight(w, 'nk'), out=out[:, :512])
+    ref = big[:, 256:512].cpu().double() @ w.cpu().double().t()
+    assert (out[:, :512].cpu().double() - ref).abs().max() < 2e-4
+    assert out[:, 512:].abs().max() == 0
+    # InstanceNorm + LeakyReLU folded into the A load: same values as the exact-f32 kernel's fused path
+    lens = np.array([700, 1300], np.int32)
+    y = (torch.randn(2000, 64, generator=g) * 3 + 1).cuda()
+    st = ops.instnorm_stats(y, seg_of(lens), int(lens.max()))
+    w2 = torch.randn(64, 128, generator=g).cuda() / 8
+    o_x3 = ops.gemm(y, ops.SplitWeight(w2, 'kn'), a_stats=st, a_seg_off=seg_of(lens))
+    o_f32 = ops.gemm(y, w2, a_stats=st, a_seg_off=seg_of(lens))
+    assert (o_x3 - o_f32).abs().max() < 2e-5 * max(1.0, o_f32.abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------ preprocessing
 def _check_subsample(pts, lens, dl):
     from oracle import native

@@ -1,0 +1,113 @@
+"""Host-side harness (test.py / demo.py plumbing): file formats, est.log writer, prefetch order, CLI error codes.
+CPU tests need no GPU; the -m gpu tests run the two CLIs end to end on synthetic files."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT
+
+
+def test_ply_reader_ascii_and_binary(tmp_path):
+    from regtr_amd.harness import load_point_cloud
+    pts = np.random.default_rng(0).standard_normal((17, 3)).astype(np.float32)
+    a = tmp_path / 'a.ply'
+    with open(a, 'w') as f:
+        f.write('ply\nformat ascii 1.0\nelement vertex 17\nproperty float x\nproperty float y\nproperty float z\nend_header\n')
+        for p in pts:
+            f.write(' '.join(repr(float(v)) for v in p) + '\n')
+    assert np.allclose(load_point_cloud(str(a)), pts, atol=1e-6)
+    b = tmp_path / 'b.ply'
+    rec = np.zeros(17, dtype=[('x', '<f8'), ('y', '<f8'), ('z', '<f8'), ('red', 'u1')])
+    rec['x'], rec['y'], rec['z'] = pts[:, 0], pts[:, 1], pts[:, 2]
+    with open(b, 'wb') as f:
+        f.write(b'ply\nformat binary_little_endian 1.0\ncomment x\nelement vertex 17\nproperty double x\nproperty double y\n'
+                b'property double z\nproperty uchar red\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n')
+        f.write(rec.tobytes())
+    assert np.array_equal(load_point_cloud(str(b)), pts.astype(np.float64))
+    torch.save(pts, tmp_path / 'c.pth')
+    assert np.array_equal(load_point_cloud(str(tmp_path / 'c.pth')), pts)
+
+
+def test_est_log_format(tmp_path):
+    """Block layout of generic_reg_model.py:276-281: 'tgt\\tsrc\\t-1' then four tab-separated rows with 12 decimals."""
+    from regtr_amd.harness import write_est_log
+    pose = np.arange(12, dtype=np.float64).reshape(3, 4) / 7
+    write_est_log(str(tmp_path), '3DMatch', [
+        {'src_path': 'test/7-scenes-redkitchen/cloud_bin_5.pth', 'tgt_path': 'test/7-scenes-redkitchen/cloud_bin_0.pth', 'pose': pose},
+        {'src_path': 'test/sun3d-x/cloud_bin_12.pth', 'tgt_path': 'test/sun3d-x/cloud_bin_3.pth', 'pose': pose}])
+    lines = open(tmp_path / '3DMatch' / '7-scenes-redkitchen' / 'est.log').read().split('\n')
+    assert lines[0] == '0\t5\t-1'
+    assert lines[1] == '\t'.join('{0:.12f}'.format(v) for v in pose[0])
+    assert lines[4] == '0.000000000000\t0.000000000000\t0.000000000000\t1.000000000000'
+    assert open(tmp_path / '3DMatch' / 'sun3d-x' / 'est.log').read().startswith('3\t12\t-1\n')
+
+
+def test_pose_errors_and_synthetic_pairs():
+    from regtr_amd.harness import SyntheticPairs, pose_errors
+    p = SyntheticPairs(3, points=2000)
+    a, b = p[1], p[1]
+    assert np.array_equal(a['src_xyz'], b['src_xyz']) and a['pose'].shape == (3, 4)
+    assert a['src_path'].split(os.path.sep)[1] == 'synthetic-scene000'
+    R = a['pose'][:, :3]
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-5)
+    rot, tr = pose_errors(a['pose'][None], a['pose'][None])
+    assert rot[0] < 0.05 and tr[0] == 0
+    g = a['pose'].copy(); g[:, 3] += [0.3, 0, 0.4]
+    assert abs(pose_errors(a['pose'][None], g[None])[1][0] - 0.5) < 1e-6
+
+
+def test_prefetcher_order_cpu():
+    from regtr_amd.harness import Prefetcher, SyntheticPairs
+    p = SyntheticPairs(5, points=1500)
+    got = []
+    for b in Prefetcher(p, [4, 0, 2, 1, 3], 2, torch.device('cpu')):
+        assert len(b['src_xyz']) == len(b['items']) and b['src_xyz'][0].dtype == torch.float32
+        got += [it['idx'] for it in b['items']]
+    assert got == [4, 0, 2, 1, 3]
+
+
+def test_cli_exit_codes(tmp_path):
+    """test.py:36-46: -1 without --config/--resume, -2 when the resume folder has no config."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--dev'], cwd=tmp_path, env=env, capture_output=True)
+    assert r.returncode == 255
+    ck = tmp_path / 'run' / 'ckpt'
+    ck.mkdir(parents=True)
+    (ck / 'model.pth').write_bytes(b'')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--dev', '--resume', str(ck / 'model.pth')], cwd=tmp_path,
+                       env=env, capture_output=True)
+    assert r.returncode == 254
+
+
+@pytest.mark.gpu
+def test_cli_test_py_synthetic(tmp_path):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--benchmark', '3DMatch', '--config',
+                        os.path.join(ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'), '--logdir', str(tmp_path / 'logs'), '--name', 't',
+                        '--synthetic', '5', '--batch', '2'], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = [d for d in os.listdir(tmp_path / 'logs')][0]
+    est = tmp_path / 'logs' / run / '3DMatch' / 'synthetic-scene000' / 'est.log'
+    lines = open(est).read().strip().split('\n')
+    assert len(lines) == 5 * 5 and lines[0] == '0\t1\t-1' and lines[5] == '2\t3\t-1'
+    assert os.path.exists(tmp_path / 'logs' / run / 'config.yaml')
+
+
+@pytest.mark.gpu
+def test_cli_demo_py(tmp_path):
+    from regtr_amd.synthetic import synth_pair
+    src, tgt = synth_pair(0, 6000)
+    d = tmp_path / 'data' / 'indoor' / 'test' / '7-scenes-redkitchen'
+    d.mkdir(parents=True)
+    torch.save(src, d / 'cloud_bin_0.pth'); torch.save(tgt, d / 'cloud_bin_5.pth')
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'demo.py'), '--example', '0', '--data_dir', str(tmp_path / 'data'),
+                        '--ckpt_dir', str(tmp_path / 'none'), '--save', str(tmp_path / 'o.npz')], cwd=tmp_path, env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    o = np.load(tmp_path / 'o.npz')
+    assert o['pose'].shape == (3, 4) and np.isfinite(o['pose']).all() and o['src2tgt'].shape == o['src_kp'].shape

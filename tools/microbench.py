@@ -27,13 +27,20 @@ def main():
     dev = 'cuda'
     print(subprocess.run('rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk|fclk" | head -5', shell=True,
                          capture_output=True, text=True).stdout)
-    print('--- gemm (M, N, K): us, TFLOP/s')
-    for M, N, K in [(2432, 256, 256), (2432, 768, 256), (2432, 1024, 256), (2432, 256, 1024), (2432, 256, 3840),
-                    (9728, 256, 256), (38912, 256, 256), (152000, 32, 480), (152000, 128, 32), (152000, 128, 64),
-                    (34000, 64, 960), (34000, 256, 64), (8192, 8192, 8192)]:
+    print('--- gemm (M, N, K): exact-f32 MFMA kernel | bf16x3 split kernel  (us, f32-equivalent TFLOP/s)')
+    for M, N, K in [(604382, 128, 32), (604382, 128, 64), (135017, 128, 32), (135017, 64, 128), (135017, 64, 960), (135017, 256, 64),
+                    (135017, 256, 128), (135017, 64, 256), (35142, 64, 960), (35142, 256, 64), (35142, 128, 256), (35142, 128, 1920),
+                    (35142, 512, 128), (35142, 512, 256), (35142, 128, 512), (9381, 128, 1920), (9381, 512, 128), (9381, 256, 512),
+                    (9381, 256, 3840), (9381, 1024, 256), (9381, 1024, 512), (9381, 256, 1024), (9381, 768, 256), (9381, 256, 256),
+                    (9381, 512, 256), (56286, 256, 256), (8192, 8192, 8192)]:
         a = torch.randn(M, K, device=dev); b = torch.randn(K, N, device=dev)
-        us = timeit(lambda: ops.gemm(a, b), reps=20 if M * N * K > 1e11 else 50)
-        print(f'  {M:7d} {N:5d} {K:5d}: {us:9.1f} us  {2 * M * N * K / us / 1e6:7.1f} TF')
+        sw = ops.SplitWeight(b, 'kn')
+        reps = 10 if M * N * K > 1e11 else 30
+        us = timeit(lambda: ops.gemm(a, b), reps=reps)
+        ops.force_x3_gemm = True
+        us3 = timeit(lambda: ops.gemm(a, sw), reps=reps)
+        ops.force_x3_gemm = False
+        print(f'  {M:7d} {N:5d} {K:5d}: {us:9.1f} us {2 * M * N * K / us / 1e6:7.1f} TF | {us3:9.1f} us {2 * M * N * K / us3 / 1e6:7.1f} TF   x{us / us3:.2f}')
     print('--- mha (tokens per cloud, clouds): us')
     for n, c in [(400, 2), (400, 8), (400, 32), (2000, 2)]:
         N = n * c
