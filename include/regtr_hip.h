@@ -116,7 +116,7 @@ int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
  * regtr_gemm_x3 then has the contract of regtr_gemm_f32 with `planes` in place of B.  Shapes it does not take
  * (regtr_gemm_x3_supported == 0: N not a multiple of 64, K not a multiple of 4) go to regtr_gemm_f32. */
 int regtr_gemm_x3_supported(int M, int N, int K);
-int regtr_gemm_x3_preferred(int M, int N, int K);   /* supported AND measured faster than regtr_gemm_f32 (K >= 128) */
+int regtr_gemm_x3_preferred(int M, int N, int K);   /* supported AND measured faster than regtr_gemm_f32 (K >= 32) */
 size_t regtr_gemm_split_weights_bytes(int N, int K);
 int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);

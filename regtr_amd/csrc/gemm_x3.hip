@@ -20,7 +20,12 @@
 // the per-lane SOURCE address).  Per k-tile: the A float4 loads and the B DMA of tile t+1 are issued, then the 48 MFMAs
 // per wave of tile t run from LDS while they are in flight (B double-buffered, A split + stored after the MFMAs);
 // two workgroups per CU interleave.  Split-K (deterministic two-pass) for small-M / deep-K shapes.
+// (Measured and dropped: an all-DMA variant -- raw float32 A tiles in a 3/4-stage LDS ring issued from inline asm with counted
+// vmcnt waits, the split done at fragment time -- ran 5-30 % SLOWER on every RegTR shape: the fragment-time split is
+// repeated by every wave sharing the rows, and these few-hundred-tile problems are bound by tile quantisation and L2
+// traffic of the 6-byte weight planes, not by prefetch depth.)
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -73,7 +78,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform (SGPR): LDS-DMA bases live in M0
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // Workgroup -> tile map, XCD aware: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The N / BN column tiles
+    // that share one A row-tile get the same b % 8 and consecutive b / 8, so the row-tile is fetched from HBM once and
+    // hit in that XCD's L2 by the others; the weight planes are small enough to live in every L2.
+    int tile_m, tile_n;
+    {
+        const int nc = g.N / BN, b = blockIdx.x, x = b & 7, q = b >> 3;
+        tile_n = q % nc;
+        tile_m = (q / nc) * 8 + x;
+        if (tile_m * BM >= g.M) return;            // grid is rounded up to 8 row-tiles (before any barrier: whole WG exits)
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int k_begin = blockIdx.z * g.k_chunk;
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int nk = (k_end - k_begin + XBK - 1) / XBK;
@@ -276,16 +291,22 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
     Wt[e] = (uint16_t)(p0 & 0xffffu); Wt[plane + e] = (uint16_t)(p1 & 0xffffu); Wt[2 * plane + e] = (uint16_t)(p2 & 0xffffu);
 }
 
-struct X3Plan { int wm, wn, splits, k_chunk; };
+struct X3Plan { int tile, splits, k_chunk; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64
 
 // tile shape and K split for a problem (host policy)
 X3Plan x3_plan(int M, int N, int K)
 {
-    X3Plan p{1, 1, 1, K};
-    auto tiles = [&](int wm, int wn) { return (long long)rg_cdiv(M, 64 * wm) * (N / (64 * wn)); };
-    if (N % 128 == 0 && tiles(2, 2) >= 448) { p.wm = 2; p.wn = 2; }
-    else if (tiles(2, 1) >= 448) { p.wm = 2; p.wn = 1; }
-    const long long tl = tiles(p.wm, p.wn);
+    X3Plan p{2, 1, K};
+    static const int forced = (getenv("REGTR_X3_TILE") && *getenv("REGTR_X3_TILE")) ? atoi(getenv("REGTR_X3_TILE")) : -1;   // development: tile A/B runs
+    if (forced >= 0 && forced <= 2 && (forced != 0 || N % 128 == 0)) { p.tile = forced; return p; }
+    auto tiles = [&](int bm, int bn) { return (long long)rg_cdiv(M, bm) * (N / bn); };
+    // Measured on MI355X (tools/microbench.py with REGTR_X3_TILE = 0 / 1 / 2): on RegTR's shapes (<= a few thousand tiles,
+    // N <= 1024) the 64 x 64 tile with four workgroups per CU wins -- occupancy hides the per-k-tile latency better than
+    // a bigger tile amortises traffic; 128 x 64 pays off for deep K on many rows, 128 x 128 only for really large GEMMs.
+    p.tile = 2;
+    if (K >= 960 && M >= 30000) p.tile = 1;
+    if (N % 128 == 0 && K >= 1024 && (long long)M * N >= (1LL << 25)) p.tile = 0;
+    const long long tl = p.tile == 0 ? tiles(128, 128) : (p.tile == 1 ? tiles(128, 64) : tiles(64, 64));
     if (tl < 384 && K >= 512) {
         int s = (int)((768 + tl - 1) / tl);
         const int max_by_k = K / 256;          // keep >= 256 of K per split
@@ -306,9 +327,9 @@ extern "C" {
 // 1 when regtr_gemm_x3 accepts the shape (otherwise use regtr_gemm_f32)
 int regtr_gemm_x3_supported(int M, int N, int K) { return (N >= 64 && N % 64 == 0 && K >= 16 && K % 4 == 0 && M >= 0) ? 1 : 0; }
 
-// 1 when the split kernel is also the FASTER choice (measured on MI355X, tools/microbench.py): with fewer than four
-// k-tiles the activation split and the un-overlapped first tile outweigh the 16/6 MFMA-rate advantage
-int regtr_gemm_x3_preferred(int M, int N, int K) { return (regtr_gemm_x3_supported(M, N, K) && K >= 128) ? 1 : 0; }
+// 1 when the split kernel is also the FASTER choice (measured on MI355X, tools/microbench.py): every supported shape with
+// at least one full k-tile; thinner contractions are pure streaming and stay on the exact-f32 kernel
+int regtr_gemm_x3_preferred(int M, int N, int K) { return (regtr_gemm_x3_supported(M, N, K) && K >= 32) ? 1 : 0; }
 
 size_t regtr_gemm_split_weights_bytes(int N, int K)
 {
@@ -351,11 +372,12 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
              p.splits > 1 ? (float*)ws : nullptr, (size_t)Npad * Kp, M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, a_slope};
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(rg_cdiv(M, 64 * p.wm), N / (64 * p.wn), p.splits);
+    const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
+    dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * (N / bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
 #define X3_LAUNCH(WM_, WN_) do { if (a_stats) k_gemm_x3<WM_, WN_, true><<<grid, 256, 0, st>>>(g); \
                                 else k_gemm_x3<WM_, WN_, false><<<grid, 256, 0, st>>>(g); } while (0)
-    if (p.wm == 2 && p.wn == 2) X3_LAUNCH(2, 2);
-    else if (p.wm == 2) X3_LAUNCH(2, 1);
+    if (p.tile == 0) X3_LAUNCH(2, 2);
+    else if (p.tile == 1) X3_LAUNCH(2, 1);
     else X3_LAUNCH(1, 1);
 #undef X3_LAUNCH
     if (p.splits > 1) k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
