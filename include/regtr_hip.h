@@ -123,7 +123,14 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  void* stream);
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, void* stream);
+/* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
+ * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud
+ * offsets of C's rows; then regtr_instnorm_finalize_tiles(stat_partial, seg_off, n_clouds, N, R, eps, stats) yields the
+ * same [n_clouds, N, 2] (mean, rstd) table as regtr_instnorm_stats(C).  R = 0 (split-K shapes): not available. */
+int regtr_gemm_x3_stat_tile_rows(int M, int N, int K);
+int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int n_clouds, int C, int tile_rows, float eps,
+                                  float* stats, void* stream);
 
 int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
                     float* y, float* y_plain, void* stream);

@@ -43,8 +43,10 @@ struct X3Args {
     const float* bias; const float* row_div; const float* residual;
     const float2* a_stats; const int* a_seg_off;
     float* partial;
+    double2* stat_partial;       // optional: per (row-tile, cloud) column sums / sums of squares of C  [slot][N]
+    const int* stat_seg_off;     // cloud offsets of the rows of C (n_stat_seg + 1)
     size_t plane;                // elements per weight plane = Npad * Kp
-    int M, N, K, Kp, lda, ldc, ldr, act, n_seg, k_chunk;
+    int M, N, K, Kp, lda, ldc, ldr, act, n_seg, k_chunk, n_stat_seg;
     float a_slope;
 };
 
@@ -64,7 +66,7 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsign
     p2 = x3_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
 }
 
-template <int WM, int WN, bool STATS>
+template <int WM, int WN, bool STATS, bool SOUT>
 __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
 {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -257,8 +259,43 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
                 if (g.act == 1) v = fmaxf(v, 0.f);
                 if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                 g.C[(size_t)row * g.ldc + col] = v;
+                if (SOUT) acc[i][j][r] = v;
             }
         }
+
+    // ---- optional: InstanceNorm statistics of the rows just produced (kpconv_blocks.py:510-519), so that no separate
+    // pass re-reads C.  For every cloud s that owns rows of this tile: per-column (sum, sum of squares) in float64 over
+    // the tile's rows of s -> stat_partial[(tile_m + s) * N + col]   (slot tile_m + s is unique: both only grow along M).
+    // regtr_instnorm_finalize_tiles adds the slots of a cloud in fixed order: deterministic, float64 like the stand-alone
+    // statistics kernel.
+    if (SOUT) {
+        double2* red = (double2*)As;                       // [2][BN], As is free after the last barrier of the k loop
+        const int row_last = min(m0 + BM, g.M) - 1;
+        const int s_lo = rg_find_segment(g.stat_seg_off, g.n_stat_seg, m0);
+        const int s_hi = rg_find_segment(g.stat_seg_off, g.n_stat_seg, row_last);
+        for (int sg = s_lo; sg <= s_hi; sg++) {            // workgroup-uniform
+            const int r_lo = g.stat_seg_off[sg], r_hi = min(g.stat_seg_off[sg + 1], g.M);
+#pragma unroll
+            for (int j = 0; j < WN; j++) {
+                double sm = 0.0, sq = 0.0;
+#pragma unroll
+                for (int i = 0; i < WM; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = m0 + (wm * WM + i) * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        if (row >= r_lo && row < r_hi) { const double v = (double)acc[i][j][r]; sm += v; sq += v * v; }
+                    }
+                sm += __shfl_xor(sm, 32, RG_WAVE); sq += __shfl_xor(sq, 32, RG_WAVE);
+                if (hi == 0) red[wm * BN + (wn * WN + j) * 32 + l31] = make_double2(sm, sq);
+            }
+            __syncthreads();
+            if (t < BN) {
+                const double2 a = red[t], b = red[BN + t];
+                g.stat_partial[(size_t)(tile_m + sg) * g.N + n0 + t] = make_double2(a.x + b.x, a.y + b.y);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
@@ -357,10 +394,24 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K)
 }
 
 // Same contract as regtr_gemm_f32 with B given as the planes written by regtr_gemm_split_weights(W, .., N, K, ..).
+// rows per statistics tile when regtr_gemm_x3 can emit InstanceNorm partial sums for this shape in its epilogue
+// (stat_partial), 0 when it cannot (split-K shapes): the caller then runs regtr_instnorm_stats on C instead.
+int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
+{
+    if (!regtr_gemm_x3_supported(M, N, K) || M < 1) return 0;
+    const X3Plan p = x3_plan(M, N, K);
+    if (p.splits > 1) return 0;
+    return p.tile == 2 ? 64 : 128;
+}
+
+// Same contract as regtr_gemm_f32 with B given as the planes written by regtr_gemm_split_weights(W, .., N, K, ..).
+// stat_partial (optional, needs regtr_gemm_x3_stat_tile_rows(M,N,K) = R > 0): (ceil(M / R) + n_stat_seg) * N double2 that
+// receive per-(row tile, cloud) column sums of C for regtr_instnorm_finalize_tiles; stat_seg_off [n_stat_seg + 1] are the
+// cloud offsets of C's rows.
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  void* stream)
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, void* stream)
 {
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
@@ -368,14 +419,19 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     if (M == 0) return RG_OK;
     const X3Plan p = x3_plan(M, N, K);
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
+    if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
     X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
-             p.splits > 1 ? (float*)ws : nullptr, (size_t)Npad * Kp, M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, a_slope};
+             p.splits > 1 ? (float*)ws : nullptr, (double2*)stat_partial, stat_seg_off, (size_t)Npad * Kp,
+             M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, n_stat_seg, a_slope};
     hipStream_t st = (hipStream_t)stream;
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
     dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * (N / bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
-#define X3_LAUNCH(WM_, WN_) do { if (a_stats) k_gemm_x3<WM_, WN_, true><<<grid, 256, 0, st>>>(g); \
-                                else k_gemm_x3<WM_, WN_, false><<<grid, 256, 0, st>>>(g); } while (0)
+#define X3_LAUNCH(WM_, WN_) do { \
+        if (a_stats) { if (stat_partial) k_gemm_x3<WM_, WN_, true, true><<<grid, 256, 0, st>>>(g); \
+                       else k_gemm_x3<WM_, WN_, true, false><<<grid, 256, 0, st>>>(g); } \
+        else { if (stat_partial) k_gemm_x3<WM_, WN_, false, true><<<grid, 256, 0, st>>>(g); \
+               else k_gemm_x3<WM_, WN_, false, false><<<grid, 256, 0, st>>>(g); } } while (0)
     if (p.tile == 0) X3_LAUNCH(2, 2);
     else if (p.tile == 1) X3_LAUNCH(2, 1);
     else X3_LAUNCH(1, 1);

@@ -82,6 +82,37 @@ __global__ void __launch_bounds__(256) k_instnorm_finalize(const double2* __rest
     }
 }
 
+// Same, from the per-(row tile, cloud) partial sums a GEMM epilogue wrote (gemm_x3.hip): the rows of cloud b live in
+// tiles off[b] / R .. (off[b+1] - 1) / R, tile t's share of cloud b is slot t + b.
+__global__ void __launch_bounds__(256) k_instnorm_finalize_tiles(const double2* __restrict__ partial, const int* __restrict__ seg_off,
+                                                                 int C, int tile_rows, float eps, float2* __restrict__ stats)
+{
+    const int b = blockIdx.y, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = rg_lane();
+    const int r0 = seg_off[b], r1 = seg_off[b + 1], n = r1 - r0;
+    double s = 0, ss = 0;
+    if (n > 0) {
+        const int t0 = r0 / tile_rows, t1 = (r1 - 1) / tile_rows;
+        for (int t = t0 + lane; t <= t1; t += RG_WAVE) {
+            const double2 p = partial[(size_t)(t + b) * C + c];
+            s += p.x; ss += p.y;
+        }
+    }
+    s = rg_wave_sum(s); ss = rg_wave_sum(ss);
+    if (lane == 0) {
+        float mean = 0.f, rstd = 0.f;
+        if (n > 0) {
+            const double m = s / n;
+            double var = ss / n - m * m;
+            if (var < 0) var = 0;
+            mean = (float)m;
+            rstd = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        stats[(size_t)b * C + c] = make_float2(mean, rstd);
+    }
+}
+
 // y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
 __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
                                                         const float2* __restrict__ stats, const float* __restrict__ res,
@@ -205,6 +236,17 @@ int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int m
     k_instnorm_partial<<<dim3(nchunk, n_clouds), 256, 0, st>>>(x, seg_off, C, nchunk, (double2*)ws);
     k_instnorm_finalize<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, eps,
                                                                          (float2*)stats);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// stats from the partial sums regtr_gemm_x3 wrote in its epilogue (tile_rows = regtr_gemm_x3_stat_tile_rows of that call)
+int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int n_clouds, int C, int tile_rows, float eps,
+                                  float* stats, void* stream)
+{
+    if (!partial || !seg_off || !stats || n_clouds < 1 || C < 1 || tile_rows < 1) return RG_ERR_ARG;
+    k_instnorm_finalize_tiles<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, (hipStream_t)stream>>>(
+        (const double2*)partial, seg_off, C, tile_rows, eps, (float2*)stats);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -126,11 +126,11 @@ class KPConv(nn.Module):
         self.kernel_points = nn.Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)   # :266
         self._cache = {}
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None, want_stats=None):
         w = _prepared(self._cache, 'w', self.weights,
                       lambda p: ops.SplitWeight(p.view(self.K * self.in_channels, self.out_channels), 'kn'))
         return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent,
-                          x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off)
+                          x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off, want_stats=want_stats)
 
 
 class UnaryBlock(nn.Module):
@@ -144,14 +144,14 @@ class UnaryBlock(nn.Module):
         self.mlp = nn.Linear(in_dim, out_dim, bias=False)
         self._cache = {}
 
-    def linear(self, x, a_stats=None, a_seg_off=None):
-        """The Linear alone; its InstanceNorm (+LeakyReLU) is folded into whichever kernel consumes the result."""
+    def linear(self, x, seg_off, max_len, a_stats=None, a_seg_off=None):
+        """The Linear and the InstanceNorm statistics of its output (from the GEMM epilogue); the normalisation itself
+        (+LeakyReLU) is folded into whichever kernel consumes the result.  -> (y, stats)"""
         wt = _prepared(self._cache, 'w', self.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
-        return ops.gemm(x, wt, a_stats=a_stats, a_seg_off=a_seg_off)
+        return ops.gemm(x, wt, a_stats=a_stats, a_seg_off=a_seg_off, want_stats=(seg_off, max_len))
 
     def forward(self, x, seg_off, max_len):
-        y = self.linear(x)
-        st = ops.instnorm_stats(y, seg_off, max_len)
+        y, st = self.linear(x, seg_off, max_len)
         return ops.instnorm_apply(y, seg_off, max_len, st, lrelu=not self.no_relu, out=y)
 
 
@@ -184,8 +184,7 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, meta):
         v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
-        y = self.KPConv(v.q_pts, v.s_pts, v.inds, x)
-        st = ops.instnorm_stats(y, v.seg_post, v.max_post)
+        y, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, want_stats=(v.seg_post, v.max_post))
         return ops.instnorm_apply(y, v.seg_post, v.max_post, st, lrelu=True, out=y)
 
 
@@ -211,20 +210,17 @@ class ResnetBottleneckBlock(nn.Module):
         v = _LevelView(meta, self.layer_ind, strided)
         # unary1 = Linear -> IN -> LReLU (:722): the IN+LReLU tail is applied on the fly inside the KPConv gather
         if isinstance(self.unary1, UnaryBlock):
-            x = self.unary1.linear(features)
-            x_st = ops.instnorm_stats(x, v.seg_pre, v.max_pre)
+            x, x_st = self.unary1.linear(features, v.seg_pre, v.max_pre)
         else:
             x, x_st = features, None
-        x = self.KPConv(v.q_pts, v.s_pts, v.inds, x, x_stats=x_st, s_seg_off=v.seg_pre, q_seg_off=v.seg_post)     # :726
+        x, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, x_stats=x_st, s_seg_off=v.seg_pre, q_seg_off=v.seg_post,
+                            want_stats=(v.seg_post, v.max_post))                                              # :726
         # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
-        st = ops.instnorm_stats(x, v.seg_post, v.max_post)
-        y = self.unary2.linear(x, a_stats=st, a_seg_off=v.seg_post)
-        y_st = ops.instnorm_stats(y, v.seg_post, v.max_post)
+        y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
         shortcut = ops.maxpool(features, v.inds) if strided else features                                     # :734-737
         sc_st = None
         if isinstance(self.unary_shortcut, UnaryBlock):
-            shortcut = self.unary_shortcut.linear(shortcut)
-            sc_st = ops.instnorm_stats(shortcut, v.seg_post, v.max_post)
+            shortcut, sc_st = self.unary_shortcut.linear(shortcut, v.seg_post, v.max_post)
         # LeakyReLU( IN(unary2) + [IN](shortcut) ) in one pass                                                :741
         return ops.instnorm_apply(y, v.seg_post, v.max_post, y_st, residual=shortcut, res_stats=sc_st, lrelu=True, out=y)
 

@@ -74,10 +74,13 @@ class SplitWeight:
                                              stream()), 'regtr_gemm_split_weights')
 
 
-def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1):
+def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1,
+         want_stats=None, eps=1e-5):
     """a (M,K) @ b with the fused epilogue of regtr_gemm_f32 / regtr_gemm_x3.  b: a (K,N) float32 tensor (exact-f32 MFMA
     kernel) or a SplitWeight (bf16x3 split kernel when the shape allows).  `a` may be a row-strided view.
-    a_stats (n_seg,K,2) + a_seg_off: A is read as LeakyReLU(InstanceNorm(a)) (per-cloud stats) on the fly."""
+    a_stats (n_seg,K,2) + a_seg_off: A is read as LeakyReLU(InstanceNorm(a)) (per-cloud stats) on the fly.
+    want_stats = (seg_off, max_len): also return the per-cloud InstanceNorm (mean, rstd) table (n_clouds,N,2) of the
+    result -- from the GEMM epilogue when the kernel supports it, else by a pass over the result."""
     L = _lib.lib()
     M, K = a.shape
     sw = b if isinstance(b, SplitWeight) else None
@@ -94,15 +97,29 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
             and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
         nb = L.regtr_gemm_x3_ws_bytes(M, N, K)
         ws = _ws(nb, a.device) if nb else None
+        R = L.regtr_gemm_x3_stat_tile_rows(M, N, K) if (want_stats is not None and M > 0) else 0
+        partial, s_off, n_clouds = None, None, 0
+        if R:
+            s_off = want_stats[0]
+            n_clouds = s_off.numel() - 1
+            partial = torch.empty((((M + R - 1) // R + n_clouds) * N, 2), dtype=torch.float64, device=a.device)
         check(L.regtr_gemm_x3(a.data_ptr(), lda, ptr(sw.planes), out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
                               residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
-                              ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_x3')
-        return out
-    nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
-    ws = _ws(nb, a.device) if nb else None
-    check(L.regtr_gemm_f32(a.data_ptr(), lda, ptr(b_kn), N, out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
-                           residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
-                           ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_f32')
+                              ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, ptr(partial), ptr(s_off), n_clouds,
+                              stream()), 'regtr_gemm_x3')
+        if R:
+            stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
+            check(L.regtr_instnorm_finalize_tiles(ptr(partial), ptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
+                  'regtr_instnorm_finalize_tiles')
+            return out, stats
+    else:
+        nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
+        ws = _ws(nb, a.device) if nb else None
+        check(L.regtr_gemm_f32(a.data_ptr(), lda, ptr(b_kn), N, out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
+                               residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
+                               ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_f32')
+    if want_stats is not None:
+        return out, instnorm_stats(out, want_stats[0], want_stats[1], eps)
     return out
 
 
@@ -134,11 +151,13 @@ def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
 
 
 # ------------------------------------------------------------------------------------------------ KPConv encoder
-def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None, slope=0.1):
+def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None, slope=0.1,
+           want_stats=None):
     """KPConv.forward (kpconv_blocks.py:269-414), non-deformable / linear / sum.
     nbr (Nq,H) i32, x (Ns,Cin), w_flat (KP*Cin, Cout) -> (Nq, Cout).
     x_stats (n_clouds,Cin,2): the input features are LeakyReLU(InstanceNorm(x)) applied on the fly (the tail of the
-    preceding UnaryBlock, kpconv_blocks.py:556-561), with s_seg_off / q_seg_off the support / query cloud offsets."""
+    preceding UnaryBlock, kpconv_blocks.py:556-561), with s_seg_off / q_seg_off the support / query cloud offsets.
+    want_stats = (seg_off, max_len) of the QUERY rows: returns (out, InstanceNorm stats of out)."""
     L = _lib.lib()
     nq, H = nbr.shape
     ns, Cin = x.shape
@@ -162,11 +181,11 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
           'regtr_kpconv_gather')
     if rec is not None:
         e1.record()
-    out = gemm(wf, w_flat, row_div=num)
+    res = gemm(wf, w_flat, row_div=num, want_stats=want_stats)       # (out, stats) when want_stats is given
     if rec is not None:
         e2.record()
-        rec.append((e0, e1, e2, nq, H, Cin, out.shape[1]))
-    return out
+        rec.append((e0, e1, e2, nq, H, Cin, (res[0] if want_stats is not None else res).shape[1]))
+    return res
 
 
 # bench.py sets this to a list to time every KPConv gather launch (HIP events on the launch stream = torch's current one)

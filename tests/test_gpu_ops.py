@@ -119,6 +119,25 @@ def test_gemm_x3_strided_and_fused_norm(x3_forced):
     assert (o_x3 - o_f32).abs().max() < 2e-5 * max(1.0, o_f32.abs().max().item())
 
 
+@pytest.mark.parametrize('lens,N,K', [([700, 1300], 128, 64), ([33, 1, 64, 7, 700, 0, 300, 2, 2, 2, 61], 64, 32),
+                                      ([5000, 30000, 1], 256, 960), ([64, 64, 128], 64, 128)])
+def test_gemm_x3_epilogue_instnorm_stats(lens, N, K, x3_forced):
+    """InstanceNorm statistics emitted by the GEMM epilogue (per row-tile / cloud partial sums, tiles straddling tiny
+    clouds included) == the stand-alone statistics pass over the result."""
+    ops = x3_forced
+    g = torch.Generator().manual_seed(sum(lens) + N)
+    M = sum(lens)
+    a = (torch.randn(M, K, generator=g) * 2 + 0.5).cuda()
+    w = torch.randn(K, N, generator=g).cuda() / K ** 0.5
+    div = torch.randint(1, 40, (M,), generator=g).float().cuda()
+    seg = seg_of(np.array(lens, np.int32))
+    out, st = ops.gemm(a, ops.SplitWeight(w, 'kn'), row_div=div, want_stats=(seg, max(lens)))
+    ref = ops.instnorm_stats(out, seg, max(lens))
+    assert torch.equal(out, ops.gemm(a, ops.SplitWeight(w, 'kn'), row_div=div))
+    assert (st[..., 0] - ref[..., 0]).abs().max() <= 1e-6 * max(1.0, ref[..., 0].abs().max().item())
+    assert ((st[..., 1] - ref[..., 1]).abs() <= 2e-6 * ref[..., 1].abs() + 1e-30).all()
+
+
 # ------------------------------------------------------------------------------------------------ preprocessing
 def _check_subsample(pts, lens, dl):
     from oracle import native
