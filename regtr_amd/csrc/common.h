@@ -55,6 +55,19 @@ __device__ __forceinline__ int rg_find_segment(const int* __restrict__ off, int 
     return lo;
 }
 
+// The same for a WAVE-UNIFORM row i, by the whole wave at once: lanes read 64 boundaries per step (one coalesced load, one
+// memory round trip) and count those <= i with a ballot -- instead of log2(nseg) DEPENDENT loads per lane.
+__device__ __forceinline__ int rg_find_segment_wave(const int* __restrict__ off, int nseg, int i)
+{
+    int seg = 0;
+    for (int base = 0; base < nseg; base += RG_WAVE) {      // boundaries off[1 .. nseg - 1]; off[b] <= i  =>  segment >= b
+        const int b = base + rg_lane() + 1;
+        const bool le = b < nseg && off[b] <= i;
+        seg += __popcll(__ballot(le));
+    }
+    return seg;
+}
+
 __device__ __forceinline__ uint32_t rg_hash64(uint64_t k)
 {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;

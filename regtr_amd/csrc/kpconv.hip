@@ -292,6 +292,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     int idx_cur = load_idx(qbase);
     Nb nb_cur = load_nb(qbase, idx_cur);
     int idx_nxt = load_idx(qbase + 1);
+    int seg_cur = 0, seg_end = -1;      // cloud of the current query and its end row (x_stats path)
 #pragma unroll 1
     for (int qq = 0; qq < MG_QPW; qq++) {
         const int q = qbase + qq;
@@ -318,7 +319,15 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
             row[j] = __float_as_uint(nb.w) + lane_off;
         }
         const float2* st = nullptr;
-        if (g.x_stats) st = g.x_stats + (size_t)rg_find_segment(g.q_seg_off, g.n_seg, q) * Cin;
+        if (g.x_stats) {
+            // q is wave-uniform and the wave's queries are consecutive: the cloud changes at most rarely, and when it does
+            // the whole wave finds it in one round trip (a per-lane binary search would be log2(n) DEPENDENT loads here)
+            if (q >= seg_end) {
+                seg_cur = rg_find_segment_wave(g.q_seg_off, g.n_seg, q);
+                seg_end = g.q_seg_off[seg_cur + 1];
+            }
+            st = g.x_stats + (size_t)seg_cur * Cin;
+        }
         const __amdgpu_buffer_rsrc_t wf_rs = rg_rsrc(g.wf + (size_t)q * g.KP * Cin, wf_q_bytes);
         Nb nb_nxt = nb_cur;
         int idx_nn = ns;

@@ -425,7 +425,7 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     const int ns = s_seg_off[n_clouds];
     const int q = blockIdx.x * QUERY_WAVES + wave;
     if (q >= nq) return;  // wave-uniform
-    const int cid = rg_find_segment(q_seg_off, n_clouds, q);
+    const int cid = rg_find_segment_wave(q_seg_off, n_clouds, q);    // q is wave-uniform: one round trip, not log2(n) dependent loads
     const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
     const float r2 = __fmul_rn(radius, radius);  // neighbors.cpp:226
 

@@ -33,9 +33,11 @@ def _scene_once(rng, side, voxel):
     p = np.concatenate(surf)
     p = p + rng.normal(scale=0.002, size=p.shape)
     key = np.floor(p / voxel).astype(np.int64)
-    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
-    out = np.zeros((len(cnt), 3))
-    np.add.at(out, inv.ravel(), p)
+    key -= key.min(0)
+    span = key.max(0) + 1
+    lin = (key[:, 0] * span[1] + key[:, 1]) * span[2] + key[:, 2]      # same lexicographic voxel order as unique(axis=0)
+    _, inv, cnt = np.unique(lin, return_inverse=True, return_counts=True)
+    out = np.stack([np.bincount(inv, weights=p[:, a], minlength=len(cnt)) for a in range(3)], 1)
     out /= cnt[:, None]
     out = out[np.argsort(_morton(np.floor(out / (4 * voxel)).astype(np.int64)), kind='stable')]
     # rows are in Morton order of 10 cm blocks: real 3DMatch fragments are spatially coherent too (median |i - j| between
