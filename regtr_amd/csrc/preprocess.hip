@@ -382,7 +382,49 @@ __global__ void __launch_bounds__(256) k_scatter_cells(const float* __restrict__
     sorted[pos] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
 }
 
+// One probe = ONE memory round trip: everything a radius query needs from a hash slot, packed into 32 bytes by
+// k_pack_slots once the cell starts are known (the separate rep / tkey / tcid / cnt / cell_start arrays would be three
+// dependent loads per probe, and the query kernel is latency bound).
+struct __align__(16) CellSlot {
+    uint64_t key;
+    int cid;
+    int used;        // >= 0: occupied
+    int cnt;
+    unsigned start;
+    int pad[2];
+};
+
+__global__ void __launch_bounds__(256) k_pack_slots(const int* __restrict__ rep, int T, const uint64_t* __restrict__ tkey,
+                                                    const int* __restrict__ tcid, const int* __restrict__ cnt,
+                                                    const uint64_t* __restrict__ cell_start, CellSlot* __restrict__ slots)
+{
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= T) return;
+    CellSlot s;
+    s.used = rep[h];
+    const bool occ = s.used >= 0;
+    s.key = occ ? tkey[h] : 0; s.cid = occ ? tcid[h] : -1; s.cnt = occ ? cnt[h] : 0; s.start = occ ? (unsigned)cell_start[h] : 0u;
+    s.pad[0] = s.pad[1] = 0;
+    slots[h] = s;
+}
+
+// lookup in the packed table: (count, start) of cell `key` of cloud `cid`, count 0 when the cell is empty
+__device__ __forceinline__ void slot_find(const CellSlot* __restrict__ slots, unsigned mask, uint64_t key, int cid, int& cnt,
+                                          int& start)
+{
+    unsigned h = rg_hash64(key ^ ((uint64_t)(cid + 1) * 0x9E3779B97F4A7C15ULL)) & mask;
+    cnt = 0; start = 0;
+    for (;;) {
+        const uint4 a = *(const uint4*)&slots[h];                 // key | cid | used
+        const uint2 b = *(const uint2*)((const char*)&slots[h] + 16);   // cnt | start
+        if ((int)a.w < 0) return;
+        if ((((uint64_t)a.y << 32) | a.x) == key && (int)a.z == cid) { cnt = (int)b.x; start = (int)b.y; return; }
+        h = (h + 1) & mask;
+    }
+}
+
 struct GridView {
+    const CellSlot* slots;
     const int* rep;
     const uint64_t* tkey;
     const int* tcid;
@@ -393,7 +435,7 @@ struct GridView {
     double inv_cs;
 };
 
-constexpr int QUERY_WAVES = 4;  // queries per 256-thread workgroup
+constexpr int QUERY_WAVES = 4;  // queries in flight per 256-thread workgroup
 
 // rank of every list entry among the n keys (keys are unique: the index is part of the key)
 // list lives in LDS; entries e = lane, lane+64, ...
@@ -417,14 +459,14 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = rg_lane();
-    // per-wave LDS: list[cap] u64, then 28 ints of run offsets + 27 ints of run starts
-    uint64_t* list = (uint64_t*)smem + (size_t)wave * cap;
-    int* runs = (int*)((uint64_t*)smem + (size_t)QUERY_WAVES * cap) + wave * 64;
+    // per-wave LDS: list[cap] u64, then 27 run offsets + 27 run deltas (64 ints)
+    uint64_t* list = (uint64_t*)smem + (size_t)wave * (cap + 32);
 
     const int nq = q_seg_off[n_clouds];
     const int ns = s_seg_off[n_clouds];
-    const int q = blockIdx.x * QUERY_WAVES + wave;
-    if (q >= nq) return;  // wave-uniform
+    // Grid-stride over the LIVE queries: the launch is sized for the level-0 capacity (live counts exist only on the
+    // device), and a level with 1/64 of the rows must not pay for 63/64 empty workgroups.
+    for (int q = blockIdx.x * QUERY_WAVES + wave; q < nq; q += gridDim.x * QUERY_WAVES) {   // wave-uniform
     const int cid = rg_find_segment_wave(q_seg_off, n_clouds, q);    // q is wave-uniform: one round trip, not log2(n) dependent loads
     const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
     const float r2 = __fmul_rn(radius, radius);  // neighbors.cpp:226
@@ -435,19 +477,23 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     int my_cnt = 0, my_start = 0;
     if (lane < 27) {
         const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
-        const int h = hash_find(g.rep, g.mask, g.tkey, g.tcid, cell_key(cx + dx, cy + dy, cz + dz), cid);
-        if (h >= 0) { my_cnt = g.cnt[h]; my_start = (int)g.cell_start[h]; }
+        slot_find(g.slots, g.mask, cell_key(cx + dx, cy + dy, cz + dz), cid, my_cnt, my_start);
     }
     // exclusive prefix of the run lengths over lanes
+    // (DPP row shifts: Hillis-Steele inside each 16-lane row, then row 0's total is added to row 1 -- the 27 runs live in
+    //  lanes 0..26; five dependent ds_bpermute shuffles would cost five LDS-crossbar round trips)
     int inc = my_cnt;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        int t = __shfl_up(inc, o, RG_WAVE);
-        if (lane >= o) inc += t;
-    }
-    const int total = __shfl(inc, 26, RG_WAVE);
-    if (lane < 27) { runs[lane] = inc - my_cnt; runs[32 + lane] = my_start; }
-    if (lane == 27) runs[27] = total;
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);     // row_shr:1, out-of-row reads 0
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);     // row_shr:2
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);     // row_shr:4
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);     // row_shr:8
+    inc += (lane >= 16 && lane < 32) ? __builtin_amdgcn_readlane(inc, 15) : 0;
+    const int total = __builtin_amdgcn_readlane(inc, 26);
+    // run table in LDS: run r covers candidates [runs[r], runs[r + 1]) and candidate t of it is support row t + runs[32 + r].
+    // (Measured: keeping the table in 54 SGPRs and selecting with 26 compare/selects per lane is SLOWER -- the kernel is
+    //  VALU-issue bound, not latency bound: the 5-step binary search costs fewer vector instructions.)
+    int* runs = (int*)(list + cap);
+    if (lane < 27) { runs[lane] = inc - my_cnt; runs[32 + lane] = my_start - (inc - my_cnt); }
     __builtin_amdgcn_wave_barrier();
 
     int n = 0;          // entries currently in the list
@@ -459,11 +505,9 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
         if (t < total) {
             int c = 0;  // last run with offset <= t
 #pragma unroll
-            for (int step = 16; step > 0; step >>= 1) {
-                const int c2 = c + step;
-                if (c2 < 27 && runs[c2] <= t) c = c2;
-            }
-            const float4 sp = g.sorted[runs[32 + c] + (t - runs[c])];
+            for (int step = 16; step > 0; step >>= 1) { const int c2 = c + step; if (c2 < 27 && runs[c2] <= t) c = c2; }
+            const int d = runs[32 + c];
+            const float4 sp = g.sorted[t + d];
             const float dx = __fsub_rn(qx, sp.x), dy = __fsub_rn(qy, sp.y), dz = __fsub_rn(qz, sp.z);
             // nanoflann.hpp:432-440 : ((0 + dx*dx) + dy*dy) + dz*dz, strict '<' (nanoflann.hpp:249-251)
             float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -504,11 +548,13 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
         if (out_count) out_count[q] = n_total;
         if (out_max_count) atomicMax(out_max_count, n_total);
     }
+    __builtin_amdgcn_wave_barrier();      // the LDS list is reused by the wave's next query
+    }
 }
 
 struct GridBuffers {
     uint64_t* pkey; int* pcid; int* slot_of; int* rep; int* cnt; int* fill;
-    uint64_t* tkey; int* tcid; uint64_t* scan_in; uint64_t* cell_start; uint64_t* bsum; float4* sorted;
+    uint64_t* tkey; int* tcid; uint64_t* scan_in; uint64_t* cell_start; uint64_t* bsum; float4* sorted; CellSlot* slots;
     unsigned T;
     size_t bytes;
 };
@@ -525,6 +571,7 @@ GridBuffers carve_grid(void* ws, size_t ws_bytes, int ns_cap)
     b.scan_in = c.take<uint64_t>(T); b.cell_start = c.take<uint64_t>(T);
     b.bsum = c.take<uint64_t>(rg_cdiv(T, SCAN_TILE) + 1);
     b.sorted = c.take<float4>(ns_cap);
+    b.slots = c.take<CellSlot>(T);
     b.bytes = rg_align_up(c.off, 256);
     return b;
 }
@@ -630,6 +677,7 @@ int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds,
     scan_u64(b.scan_in, tn, (int)b.T, b.bsum, b.cell_start, st);
     if (ns_cap > 0)
         k_scatter_cells<<<rg_cdiv(ns_cap, 256), 256, 0, st>>>(s_xyz, n_ptr, b.slot_of, b.cell_start, b.fill, b.sorted);
+    k_pack_slots<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, (int)b.T, b.tkey, b.tcid, b.cnt, b.cell_start, b.slots);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
@@ -647,14 +695,15 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     if (nq_cap <= 0) return RG_OK;
     hipStream_t st = (hipStream_t)stream;
     GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap > 0 ? ns_cap : 1);
-    GridView g{b.rep, b.tkey, b.tcid, b.cell_start, b.cnt, b.sorted, b.T - 1, 1.0 / ((double)radius * (1.0 + 1e-6))};
+    GridView g{b.slots, b.rep, b.tkey, b.tcid, b.cell_start, b.cnt, b.sorted, b.T - 1, 1.0 / ((double)radius * (1.0 + 1e-6))};
     // LDS list capacity per query: room for the K survivors of a shrink plus one 64-candidate round
     int cap = (2 * K + 63) / 64 * 64;
     if (cap < 256) cap = 256;
     if (cap > 512) cap = 512;          // 8 register-staged chunks of 64 in the shrink path
     if (cap < K + RG_WAVE) return RG_ERR_ARG;   // K <= 448
-    const size_t lds = (size_t)QUERY_WAVES * cap * sizeof(uint64_t) + (size_t)QUERY_WAVES * 64 * sizeof(int);
-    k_radius_query<<<rg_cdiv(nq_cap, QUERY_WAVES), QUERY_WAVES * RG_WAVE, lds, st>>>(
+    const size_t lds = (size_t)QUERY_WAVES * (cap + 32) * sizeof(uint64_t);
+    const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_cdiv(nq_cap, QUERY_WAVES) : 256 * 64;   // grid-stride inside
+    k_radius_query<<<grid, QUERY_WAVES * RG_WAVE, lds, st>>>(
         q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, out_idx, out_count, out_max_count);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
