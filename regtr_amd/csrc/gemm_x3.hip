@@ -66,19 +66,21 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsign
     p2 = x3_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
 }
 
-template <int WM, int WN, bool STATS, bool SOUT>
-__global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
+template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT>      // MW x NW waves, wave tile (32 WM) x (32 WN)
+__global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x3(X3Args g)
 {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int AV = BM / 32;                   // float4 of A per thread per tile
-    constexpr int NQ = 3 * BN / 64;               // LDS-DMA instructions (1 KiB each) per wave per tile
+    constexpr int NT = 64 * MW * NW, RPP = NT / 8; // threads; A rows staged per pass (8 float4 per row)
+    constexpr int BM = 32 * WM * MW, BN = 32 * WN * NW;
+    constexpr int AV = BM / RPP;                  // float4 of A per thread per tile
+    constexpr int NQ = 3 * BN / (16 * MW * NW);   // LDS-DMA instructions (1 KiB each) per wave per tile
+    static_assert(BM % RPP == 0 && (3 * BN) % (16 * MW * NW) == 0, "tile must split evenly over the waves");
     constexpr int A_BYTES = 3 * BM * XROW, B_BYTES = 3 * BN * XROW;
     __shared__ __align__(1024) unsigned char As[A_BYTES];
     __shared__ __align__(1024) unsigned char Bs0[B_BYTES];     // two SEPARATE objects: the compiler can then tell that the
     __shared__ __align__(1024) unsigned char Bs1[B_BYTES];     // DMA into one does not alias fragment reads of the other
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // wave-uniform (SGPR): LDS-DMA bases live in M0
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NW, wn = wave % NW;
     const int l31 = lane & 31, hi = lane >> 5;
     // Workgroup -> tile map, XCD aware: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The N / BN column tiles
     // that share one A row-tile get the same b % 8 and consecutive b / 8, so the row-tile is fetched from HBM once and
@@ -95,7 +97,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
     const int k_end = min(g.K, k_begin + g.k_chunk);
     const int nk = (k_end - k_begin + XBK - 1) / XBK;
 
-    // ---- A staging: float4 #i of this thread = row (t / 8 + 32 i), k4 = (t % 8) * 4.  Loads are branch free (clamped
+    // ---- A staging: float4 #i of this thread = row (t / 8 + RPP i), k4 = (t % 8) * 4.  Loads are branch free (clamped
     // address + select) so that nothing splits the loop body into blocks the compiler would drain loads at.
     const int a_row = t >> 3, a_k4 = (t & 7) * 4;
     const float* a_ptr[AV];
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
     bool a_ok[AV];
 #pragma unroll
     for (int i = 0; i < AV; i++) {
-        const int row = m0 + a_row + 32 * i;
+        const int row = m0 + a_row + RPP * i;
         a_ok[i] = row < g.M;
         const int rc = a_ok[i] ? row : g.M - 1;
         a_ptr[i] = g.A + (size_t)rc * g.lda;
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
             unsigned p0a, p1a, p2a, p0b, p1b, p2b;
             x3_split2(v.x, v.y, p0a, p1a, p2a);
             x3_split2(v.z, v.w, p0b, p1b, p2b);
-            unsigned char* dst = As + a_st_off + i * 32 * XROW;
+            unsigned char* dst = As + a_st_off + i * RPP * XROW;
             *(uint2*)(dst) = make_uint2(p0a, p0b);
             *(uint2*)(dst + BM * XROW) = make_uint2(p1a, p1b);
             *(uint2*)(dst + 2 * BM * XROW) = make_uint2(p2a, p2b);
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
     // regtr_instnorm_finalize_tiles adds the slots of a cloud in fixed order: deterministic, float64 like the stand-alone
     // statistics kernel.
     if (SOUT) {
-        double2* red = (double2*)As;                       // [2][BN], As is free after the last barrier of the k loop
+        double2* red = (double2*)As;                       // [MW][BN], As is free after the last barrier of the k loop
         const int row_last = min(m0 + BM, g.M) - 1;
         const int s_lo = rg_find_segment(g.stat_seg_off, g.n_stat_seg, m0);
         const int s_hi = rg_find_segment(g.stat_seg_off, g.n_stat_seg, row_last);
@@ -290,8 +292,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3(X3Args g)
             }
             __syncthreads();
             if (t < BN) {
-                const double2 a = red[t], b = red[BN + t];
-                g.stat_partial[(size_t)(tile_m + sg) * g.N + n0 + t] = make_double2(a.x + b.x, a.y + b.y);
+                double2 a = red[t];
+#pragma unroll
+                for (int w = 1; w < MW; w++) { const double2 b = red[w * BN + t]; a.x += b.x; a.y += b.y; }
+                g.stat_partial[(size_t)(tile_m + sg) * g.N + n0 + t] = a;
             }
             __syncthreads();
         }
@@ -337,12 +341,13 @@ X3Plan x3_plan(int M, int N, int K)
     static const int forced = (getenv("REGTR_X3_TILE") && *getenv("REGTR_X3_TILE")) ? atoi(getenv("REGTR_X3_TILE")) : -1;   // development: tile A/B runs
     if (forced >= 0 && forced <= 2 && (forced != 0 || N % 128 == 0)) { p.tile = forced; return p; }
     auto tiles = [&](int bm, int bn) { return (long long)rg_cdiv(M, bm) * (N / bn); };
-    // Measured on MI355X (tools/microbench.py with REGTR_X3_TILE = 0 / 1 / 2): on RegTR's shapes (<= a few thousand tiles,
-    // N <= 1024) the 64 x 64 tile with four workgroups per CU wins -- occupancy hides the per-k-tile latency better than
-    // a bigger tile amortises traffic; 128 x 64 pays off for deep K on many rows, 128 x 128 only for really large GEMMs.
+    // Measured on MI355X (REGTR_X3_TILE = 0 / 1 / 2 sweeps over RegTR's shapes at 16 and 64 pairs per forward): with a few
+    // hundred tiles the 64 x 64 tile at four workgroups per CU wins (occupancy hides the per-k-tile latency); from about
+    // six tiles per CU on, the larger tiles' lower operand traffic per flop pays: 128 x 64 first for deep K, then the
+    // 8-wave 128 x 128 tile.
     p.tile = 2;
-    if (K >= 960 && M >= 30000) p.tile = 1;
-    if (N % 128 == 0 && K >= 1024 && (long long)M * N >= (1LL << 25)) p.tile = 0;
+    if (tiles(128, 64) >= 512 && (K >= 960 || tiles(128, 64) >= 2048)) p.tile = 1;
+    if (N % 128 == 0 && tiles(128, 128) >= 1536) p.tile = 0;
     const long long tl = p.tile == 0 ? tiles(128, 128) : (p.tile == 1 ? tiles(128, 64) : tiles(64, 64));
     if (tl < 384 && K >= 512) {
         int s = (int)((768 + tl - 1) / tl);
@@ -427,14 +432,14 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     hipStream_t st = (hipStream_t)stream;
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
     dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * (N / bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
-#define X3_LAUNCH(WM_, WN_) do { \
-        if (a_stats) { if (stat_partial) k_gemm_x3<WM_, WN_, true, true><<<grid, 256, 0, st>>>(g); \
-                       else k_gemm_x3<WM_, WN_, true, false><<<grid, 256, 0, st>>>(g); } \
-        else { if (stat_partial) k_gemm_x3<WM_, WN_, false, true><<<grid, 256, 0, st>>>(g); \
-               else k_gemm_x3<WM_, WN_, false, false><<<grid, 256, 0, st>>>(g); } } while (0)
-    if (p.tile == 0) X3_LAUNCH(2, 2);
-    else if (p.tile == 1) X3_LAUNCH(2, 1);
-    else X3_LAUNCH(1, 1);
+#define X3_LAUNCH(MW_, NW_, WM_, WN_) do { \
+        if (a_stats) { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, true, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+                       else k_gemm_x3<MW_, NW_, WM_, WN_, true, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \
+        else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+               else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)
+    if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);          // 128 x 128, 8 waves of 64 x 32
+    else if (p.tile == 1) X3_LAUNCH(2, 2, 2, 1);     // 128 x 64, 4 waves of 64 x 32
+    else X3_LAUNCH(2, 2, 1, 1);                      // 64 x 64, 4 waves of 32 x 32
 #undef X3_LAUNCH
     if (p.splits > 1) k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
     RG_RETURN_IF_LAUNCH_FAILED();
