@@ -51,3 +51,50 @@ def test_shard_pairs_partition():
         parts = [shard_pairs(n, r, w) for r in range(w)]
         assert sorted(sum(parts, [])) == list(range(n))
         assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+class _StubModel(torch.nn.Module):
+    """Stands in for RegTR in the harness test: a 'pose' that is a known function of the pair's clouds."""
+
+    def forward(self, batch):
+        B = len(batch['src_xyz'])
+        pose = torch.zeros(6, B, 3, 4)
+        for b in range(B):
+            pose[-1, b, :, 3] = batch['src_xyz'][b].mean(0)
+            pose[-1, b, :, :3] = torch.eye(3) * float(len(batch['tgt_xyz'][b]))
+        return {'pose': pose}
+
+
+def _harness_worker(rank, world, port, n_pairs, batch, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from regtr_amd import harness
+    pairs = harness.SyntheticPairs(n_pairs, points=1500)
+    poses, ids, timing = harness.run_test(_StubModel(), pairs, batch, torch.device('cpu'))
+    q.put((rank, poses.copy(), ids.copy(), timing['world']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_harness_run_test_world2():
+    """test.py's loop on 2 ranks (gloo): ragged shards (5 pairs, batches of 2), every rank ends with all poses in pair order."""
+    import numpy as np
+    from regtr_amd import harness
+    n_pairs = 5
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harness_worker, args=(r, 2, port, n_pairs, 2, q)) for r in range(2)]
+    for p in procs: p.start()
+    results = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pairs = harness.SyntheticPairs(n_pairs, points=1500)
+    for _, poses, ids, world in results:
+        assert world == 2 and ids.tolist() == list(range(n_pairs)) and poses.shape == (n_pairs, 3, 4)
+        for i in range(n_pairs):
+            it = pairs[i]
+            assert np.allclose(poses[i][:, 3], it['src_xyz'].mean(0), atol=1e-5)
+            assert poses[i][0, 0] == float(len(it['tgt_xyz']))
