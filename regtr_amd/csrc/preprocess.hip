@@ -490,8 +490,9 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     inc += (lane >= 16 && lane < 32) ? __builtin_amdgcn_readlane(inc, 15) : 0;
     const int total = __builtin_amdgcn_readlane(inc, 26);
     // run table in LDS: run r covers candidates [runs[r], runs[r + 1]) and candidate t of it is support row t + runs[32 + r].
-    // (Measured: keeping the table in 54 SGPRs and selecting with 26 compare/selects per lane is SLOWER -- the kernel is
-    //  VALU-issue bound, not latency bound: the 5-step binary search costs fewer vector instructions.)
+    // (Measured and dropped: the table in 54 SGPRs with 26 compare/selects per lane instead of the 5-step LDS binary
+    //  search: 17 % slower; two queries per wave, one per 32-lane half, with per-half DPP scans / ballots: 17 % slower too,
+    //  bit-identical tables in both cases.)
     int* runs = (int*)(list + cap);
     if (lane < 27) { runs[lane] = inc - my_cnt; runs[32 + lane] = my_start - (inc - my_cnt); }
     __builtin_amdgcn_wave_barrier();
