@@ -62,8 +62,33 @@ def traffic_json(out, kernel_sub, calib_sub='k_instnorm_partial'):
     print(json.dumps(res, indent=1))
 
 
+def mfma_table(out):
+    """Matrix-core utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), kernel cycles =
+    GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); plus the wave-cycle split (SQ_* are quad-cycles)."""
+    vals = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
+    for f in sorted(glob.glob(f'{out}/pmc_*/**/*counter_collection.csv', recursive=True)):
+        seen = set()
+        for row in csv.DictReader(open(f)):
+            k = short(row['Kernel_Name'])
+            vals[k][row['Counter_Name']] += float(row['Counter_Value'])
+            if row['Counter_Name'] == 'GRBM_GUI_ACTIVE' and row['Dispatch_Id'] not in seen:
+                seen.add(row['Dispatch_Id']); cnt[k] += 1
+    print('| kernel | launches | MFMA busy % of SIMD-cycles | wave cycles: waitcnt % | issue stall % | VALU % | MFMA instr / launch |')
+    print('|---|---|---|---|---|---|---|')
+    for k in sorted(vals, key=lambda k: -vals[k].get('GRBM_GUI_ACTIVE', 0)):
+        v = vals[k]
+        if not v.get('GRBM_GUI_ACTIVE') or not v.get('SQ_WAVE_CYCLES'):
+            continue
+        util = 100 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (v['GRBM_GUI_ACTIVE'] / 8 * 1024)
+        wc = v['SQ_WAVE_CYCLES']
+        print(f"| {k} | {cnt[k]} | {util:.1f} | {100 * v.get('SQ_WAIT_ANY', 0) / wc:.0f} | {100 * v.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} | "
+              f"{100 * v.get('SQ_ACTIVE_INST_VALU', 0) / wc:.0f} | {v.get('SQ_INSTS_MFMA', 0) / max(cnt[k], 1):.3g} |")
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 2 and sys.argv[1] == '--traffic':
+    if len(sys.argv) > 2 and sys.argv[1] == '--mfma':
+        mfma_table(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[1] == '--traffic':
         traffic_json(*sys.argv[2:4])
     else:
         main(*sys.argv[1:3])
