@@ -234,7 +234,7 @@ def main():
             traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r)
             res['roofline'] = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
             res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(4)])
         print(json.dumps(res))
     if dist:

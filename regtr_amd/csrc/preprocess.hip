@@ -5,8 +5,9 @@
 // (paths relative to /root/reference/src/models/backbone_kpconv/).
 //
 // Design (not a translation -- the reference is a hash-map loop and a KD-tree):
-//   * one spatial hash per call, open addressing over int32 "representative point" slots, sized
-//     2x the point capacity.  HBM is plentiful (288 GB) so every per-point intermediate is kept.
+//   * one spatial hash per call, open addressing over int32 "representative point" slots, allocated for
+//     1.5x the point capacity and sized on the device for the live count.  HBM is plentiful (288 GB) so
+//     every per-point intermediate is kept.
 //   * all sizes that depend on the data (points per level) stay ON THE DEVICE: kernels are launched
 //     over the caller's capacity and read the live counts from the segment-offset arrays, so a whole
 //     pyramid is enqueued without a single host round trip.
@@ -115,6 +116,32 @@ int scan_u64(const uint64_t* in, const int* n_ptr, int n_cap, uint64_t* bsum, ui
 // ------------------------------------------------------------------------------------------------
 // spatial hash: slots hold the index of the first point that claimed them ("representative")
 // ------------------------------------------------------------------------------------------------
+// Hash tables are ALLOCATED for the level-0 capacity (live counts exist only on the device) but SIZED, on the device, for
+// the live count of their level: the power of two >= 1.5 n (>= 64).  Clears, key passes, scans and the packed-slot pass
+// then touch 1.5-3 n slots instead of 3 x capacity, and probes of a deep level stay in a table 1/64 the size.
+__device__ __forceinline__ unsigned rg_live_table(int n)
+{
+    unsigned want = (unsigned)n + ((unsigned)n >> 1);
+    if (want < 64u) want = 64u;
+    return 1u << (32 - __clz((int)(want - 1u)));
+}
+static inline unsigned rg_table_capacity(int n_cap)       // host twin: upper bound of rg_live_table over n <= n_cap
+{
+    unsigned want = (unsigned)n_cap + ((unsigned)n_cap >> 1);
+    if (want < 64u) want = 64u;
+    return rg_next_pow2(want);
+}
+
+__global__ void __launch_bounds__(256) k_clear_tables(const int* __restrict__ n_ptr, int* __restrict__ rep, int* __restrict__ cnt,
+                                                      int* __restrict__ fill, int* __restrict__ first)
+{
+    const unsigned T = rg_live_table(*n_ptr);
+    const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= T) return;
+    rep[h] = -1; cnt[h] = 0; fill[h] = 0;
+    if (first) first[h] = 0x7F7F7F7F;
+}
+
 __device__ __forceinline__ int hash_insert(int* __restrict__ rep, unsigned mask, const uint64_t* __restrict__ pkey,
                                            const int* __restrict__ pcid, int i, uint64_t key, int cid)
 {
@@ -240,13 +267,13 @@ __global__ void __launch_bounds__(256) k_voxel_keys(const float* __restrict__ xy
 }
 
 __global__ void __launch_bounds__(256) k_insert(const int* __restrict__ n_ptr, const uint64_t* __restrict__ pkey,
-                                                const int* __restrict__ pcid, int* __restrict__ rep, unsigned mask,
+                                                const int* __restrict__ pcid, int* __restrict__ rep,
                                                 int* __restrict__ slot_of, int* __restrict__ first, int* __restrict__ cnt)
 {
     const int n = *n_ptr;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int s = hash_insert(rep, mask, pkey, pcid, i, pkey[i], pcid[i]);
+    const int s = hash_insert(rep, rg_live_table(n) - 1u, pkey, pcid, i, pkey[i], pcid[i]);
     slot_of[i] = s;
     if (first) atomicMin(&first[s], i);
     atomicAdd(&cnt[s], 1);
@@ -354,15 +381,16 @@ __global__ void __launch_bounds__(256) k_cell_keys(const float* __restrict__ xyz
     pcid[i] = rg_find_segment(seg_off, n_clouds, i);
 }
 
-__global__ void k_set_int(int* p, int v) { *p = v; }
-
 // slot -> (cell key, cloud) for lookups, and the scan input (member count per slot)
-__global__ void __launch_bounds__(256) k_table_keys(const int* __restrict__ rep, int T, const uint64_t* __restrict__ pkey,
+__global__ void __launch_bounds__(256) k_table_keys(const int* __restrict__ rep, const int* __restrict__ n_ptr,
+                                                    const uint64_t* __restrict__ pkey,
                                                     const int* __restrict__ pcid, const int* __restrict__ cnt,
                                                     uint64_t* __restrict__ tkey, int* __restrict__ tcid,
-                                                    uint64_t* __restrict__ scan_in)
+                                                    uint64_t* __restrict__ scan_in, int* __restrict__ table_len)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = (int)rg_live_table(*n_ptr);
+    if (h == 0) *table_len = T;            // device-side length of the scan over the table
     if (h >= T) return;
     const int r = rep[h];
     if (r >= 0) { tkey[h] = pkey[r]; tcid[h] = pcid[r]; }
@@ -394,12 +422,13 @@ struct __align__(16) CellSlot {
     int pad[2];
 };
 
-__global__ void __launch_bounds__(256) k_pack_slots(const int* __restrict__ rep, int T, const uint64_t* __restrict__ tkey,
+__global__ void __launch_bounds__(256) k_pack_slots(const int* __restrict__ rep, const int* __restrict__ n_ptr,
+                                                    const uint64_t* __restrict__ tkey,
                                                     const int* __restrict__ tcid, const int* __restrict__ cnt,
                                                     const uint64_t* __restrict__ cell_start, CellSlot* __restrict__ slots)
 {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= T) return;
+    if (h >= (int)rg_live_table(*n_ptr)) return;
     CellSlot s;
     s.used = rep[h];
     const bool occ = s.used >= 0;
@@ -431,7 +460,6 @@ struct GridView {
     const uint64_t* cell_start;
     const int* cnt;
     const float4* sorted;
-    unsigned mask;
     double inv_cs;
 };
 
@@ -464,6 +492,7 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
 
     const int nq = q_seg_off[n_clouds];
     const int ns = s_seg_off[n_clouds];
+    const unsigned mask = rg_live_table(ns) - 1u;      // the table was built for ns supports
     // Grid-stride over the LIVE queries: the launch is sized for the level-0 capacity (live counts exist only on the
     // device), and a level with 1/64 of the rows must not pay for 63/64 empty workgroups.
     for (int q = blockIdx.x * QUERY_WAVES + wave; q < nq; q += gridDim.x * QUERY_WAVES) {   // wave-uniform
@@ -477,7 +506,7 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     int my_cnt = 0, my_start = 0;
     if (lane < 27) {
         const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
-        slot_find(g.slots, g.mask, cell_key(cx + dx, cy + dy, cz + dz), cid, my_cnt, my_start);
+        slot_find(g.slots, mask, cell_key(cx + dx, cy + dy, cz + dz), cid, my_cnt, my_start);
     }
     // exclusive prefix of the run lengths over lanes
     // (DPP row shifts: Hillis-Steele inside each 16-lane row, then row 0's total is added to row 1 -- the 27 runs live in
@@ -564,7 +593,7 @@ GridBuffers carve_grid(void* ws, size_t ws_bytes, int ns_cap)
 {
     GridBuffers b;
     RgCarver c(ws, ws_bytes);
-    const unsigned T = rg_next_pow2((unsigned)(2 * (ns_cap > 32 ? ns_cap : 32)));
+    const unsigned T = rg_table_capacity(ns_cap);
     b.T = T;
     b.pkey = c.take<uint64_t>(ns_cap); b.pcid = c.take<int>(ns_cap); b.slot_of = c.take<int>(ns_cap);
     b.rep = c.take<int>(T); b.cnt = c.take<int>(T); b.fill = c.take<int>(T);
@@ -588,7 +617,7 @@ SubsampleBuffers carve_subsample(void* ws, size_t ws_bytes, int n_cap, int n_clo
 {
     SubsampleBuffers b;
     RgCarver c(ws, ws_bytes);
-    b.T = rg_next_pow2((unsigned)(2 * (n_cap > 32 ? n_cap : 32)));
+    b.T = rg_table_capacity(n_cap);
     b.pkey = c.take<uint64_t>(n_cap); b.scan_in = c.take<uint64_t>(n_cap); b.scan_out = c.take<uint64_t>(n_cap);
     b.pcid = c.take<int>(n_cap); b.slot_of = c.take<int>(n_cap); b.members = c.take<int>(n_cap);
     b.rep = c.take<int>(b.T); b.first = c.take<int>(b.T); b.cnt = c.take<int>(b.T); b.fill = c.take<int>(b.T);
@@ -627,14 +656,11 @@ int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int
     const int* n_ptr = seg_off + n_clouds;
     const int nb = rg_cdiv(n_cap, 256);
 
-    (void)hipMemsetAsync(rep, 0xFF, sizeof(int) * T, st);
-    (void)hipMemsetAsync(first, 0x7F, sizeof(int) * T, st);
-    (void)hipMemsetAsync(cnt, 0, sizeof(int) * T, st);
-    (void)hipMemsetAsync(fill, 0, sizeof(int) * T, st);
+    k_clear_tables<<<rg_cdiv(T, 256), 256, 0, st>>>(n_ptr, rep, cnt, fill, first);
     k_init_bbox<<<rg_cdiv(n_clouds * 6, 256), 256, 0, st>>>(bbox, n_clouds);
     k_bbox<<<rg_cdiv(n_cap, 256 * BBOX_ITEMS), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
     k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, pkey);
-    k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, T - 1, slot_of, first, cnt);
+    k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, slot_of, first, cnt);
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);
     scan_u64(scan_in, n_ptr, n_cap, bsum, scan_out, st);
     k_scatter_members<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, scan_out, fill, members);
@@ -663,22 +689,19 @@ int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds,
     GridBuffers b = carve_grid(ws, ws_bytes, cap);
     const int* n_ptr = s_seg_off + n_clouds;
     const double inv_cs = 1.0 / ((double)radius * (1.0 + 1e-6));
-    (void)hipMemsetAsync(b.rep, 0xFF, sizeof(int) * b.T, st);
-    (void)hipMemsetAsync(b.cnt, 0, sizeof(int) * b.T, st);
-    (void)hipMemsetAsync(b.fill, 0, sizeof(int) * b.T, st);
+    k_clear_tables<<<rg_cdiv(b.T, 256), 256, 0, st>>>(n_ptr, b.rep, b.cnt, b.fill, nullptr);
     if (ns_cap > 0) {
         const int nb = rg_cdiv(ns_cap, 256);
         k_cell_keys<<<nb, 256, 0, st>>>(s_xyz, s_seg_off, n_clouds, inv_cs, b.pkey, b.pcid);
-        k_insert<<<nb, 256, 0, st>>>(n_ptr, b.pkey, b.pcid, b.rep, b.T - 1, b.slot_of, nullptr, b.cnt);
+        k_insert<<<nb, 256, 0, st>>>(n_ptr, b.pkey, b.pcid, b.rep, b.slot_of, nullptr, b.cnt);
     }
-    k_table_keys<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, (int)b.T, b.pkey, b.pcid, b.cnt, b.tkey, b.tcid, b.scan_in);
-    // the table length is a host constant: reuse the device-n scan with n = T stored in bsum's tail
+    // the live table length is computed on the device and kept in bsum's tail for the device-n scan
     int* tn = (int*)(b.bsum + rg_cdiv(b.T, SCAN_TILE));
-    k_set_int<<<1, 1, 0, st>>>(tn, (int)b.T);
+    k_table_keys<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, n_ptr, b.pkey, b.pcid, b.cnt, b.tkey, b.tcid, b.scan_in, tn);
     scan_u64(b.scan_in, tn, (int)b.T, b.bsum, b.cell_start, st);
     if (ns_cap > 0)
         k_scatter_cells<<<rg_cdiv(ns_cap, 256), 256, 0, st>>>(s_xyz, n_ptr, b.slot_of, b.cell_start, b.fill, b.sorted);
-    k_pack_slots<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, (int)b.T, b.tkey, b.tcid, b.cnt, b.cell_start, b.slots);
+    k_pack_slots<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, n_ptr, b.tkey, b.tcid, b.cnt, b.cell_start, b.slots);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
@@ -696,7 +719,7 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     if (nq_cap <= 0) return RG_OK;
     hipStream_t st = (hipStream_t)stream;
     GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap > 0 ? ns_cap : 1);
-    GridView g{b.slots, b.rep, b.tkey, b.tcid, b.cell_start, b.cnt, b.sorted, b.T - 1, 1.0 / ((double)radius * (1.0 + 1e-6))};
+    GridView g{b.slots, b.rep, b.tkey, b.tcid, b.cell_start, b.cnt, b.sorted, 1.0 / ((double)radius * (1.0 + 1e-6))};
     // LDS list capacity per query: room for the K survivors of a shrink plus one 64-candidate round
     int cap = (2 * K + 63) / 64 * 64;
     if (cap < 256) cap = 256;
