@@ -38,9 +38,8 @@ def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
 
 
 def measure_kpconv_roofline(model, batch, reps=5):
-    """Times every KPConv gather launch (k_kpconv_gather_mfma: the 10 blocks with Cin >= 32; the Cin = 1 first block is a
-    fused gather + contraction kernel and not part of this figure) with HIP events on the stream it is enqueued on
-    (torch's current stream) during real forwards; achieved = sum of algorithmic bytes / sum of durations."""
+    """Times every KPConv gather launch (k_kpconv_gather) with HIP events on the stream it is enqueued on (torch's
+    current stream) during real forwards; achieved = sum of algorithmic bytes / sum of durations."""
     from regtr_amd import ops
     records = []
     ops.gather_records = records

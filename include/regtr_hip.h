@@ -88,13 +88,6 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
                         void* stream);
 
-/* KPConv.forward for Cin == 1 (first encoder block, kpconv_blocks.py:269-414 with features = ones), gather and
- * kernel-point contraction in one kernel: out [nq,Cout] = (sum_k WF[q,k] weights[k,:]) / max(1, #positive neighbours);
- * weights [KP,Cout] float32, KP <= 15, Cout % 4 == 0. */
-int regtr_kpconv_c1_fused(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                          const float* kernel_points, int KP, float extent, const float* weights, int Cout, float* out,
-                          void* stream);
-
 int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream);
 
 size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C);

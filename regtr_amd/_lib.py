@@ -29,7 +29,6 @@ SIGNATURES = {
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
     'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
-    'regtr_kpconv_c1_fused': (_I, [_P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _I, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),

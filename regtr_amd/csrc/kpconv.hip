@@ -447,79 +447,6 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
     if (k == 0) g.num[q] = fmaxf(cnt, 1.f);
 }
 
-// The whole first encoder block's KPConv (Cin == 1) in one kernel: the 15 weighted features of a query never leave the
-// chip -- they go through a 64-byte LDS row and are contracted with W [KP, Cout] (staged in LDS) by the query's 16 lanes,
-// 4 output channels per lane per pass, then divided by the normaliser.  Saves the [Nq, 15] round trip and a K = 15 GEMM
-// launch that is pure streaming.
-__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_c1_fused(GatherArgs g, const float* __restrict__ W, int Cout,
-                                                                           float* __restrict__ out)
-{
-    constexpr int QW = 4;
-    extern __shared__ __align__(16) float smem[];
-    const int wave = threadIdx.x >> 6, lane = rg_lane();
-    const int H = g.H;
-    float* w_s = smem;                                                    // W [KP_PAD][Cout] (row 15 = 0)
-    float* wf_s = w_s + KP_PAD * Cout + (size_t)wave * QW * KP_PAD;       // wf[QW][16]
-    float* rel_s = w_s + KP_PAD * Cout + GATHER_WAVES * QW * KP_PAD + (size_t)wave * QW * H * 5;   // rel[QW][H][3] | x | flag
-    float* xs_s = rel_s + QW * H * 3;
-    float* flg_s = xs_s + QW * H;
-    for (int e = threadIdx.x; e < KP_PAD * Cout; e += blockDim.x) w_s[e] = e < g.KP * Cout ? W[e] : 0.f;
-    __syncthreads();
-    const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
-    if (q0 >= g.nq) return;
-    for (int e = lane; e < QW * H; e += RG_WAVE) {
-        const int qi = e / H, h = e - qi * H, q = q0 + qi;
-        float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f, x1 = 0.f;
-        if (q < g.nq) {
-            const int idx = g.nbr[(size_t)q * H + h];
-            float sx = 1e6f, sy = 1e6f, sz = 1e6f;
-            if (idx < g.ns) {
-                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
-                x1 = g.x[idx]; f = x1 > 0.f ? 1.f : 0.f;
-            }
-            rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
-        }
-        rel_s[3 * e] = rx; rel_s[3 * e + 1] = ry; rel_s[3 * e + 2] = rz; xs_s[e] = x1; flg_s[e] = f;
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int qi = lane >> 4, k = lane & 15, q = q0 + qi;
-    const bool kvalid = k < g.KP;
-    const float kx = kvalid ? g.kp[3 * k] : 1e30f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
-    const float inv_extent = 1.0f / g.extent;
-    float acc = 0.f, cnt = 0.f;
-    for (int h = 0; h < H; h++) {
-        const int e = qi * H + h;
-        const float dx = rel_s[3 * e] - kx, dy = rel_s[3 * e + 1] - ky, dz = rel_s[3 * e + 2] - kz;
-        float d2;
-        {
-#pragma clang fp contract(off)
-            d2 = (dx * dx + dy * dy) + dz * dz;
-        }
-        const float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);      // k = 15: infinitely far, 0
-        acc = fmaf(wv, xs_s[e], acc);
-        cnt += flg_s[e];
-    }
-    wf_s[qi * KP_PAD + k] = acc;
-    __builtin_amdgcn_wave_barrier();
-    if (q >= g.nq) return;
-    float wf[KP_PAD];
-#pragma unroll
-    for (int j = 0; j < KP_PAD / 4; j++) {
-        const float4 v = *(const float4*)(wf_s + qi * KP_PAD + 4 * j);
-        wf[4 * j] = v.x; wf[4 * j + 1] = v.y; wf[4 * j + 2] = v.z; wf[4 * j + 3] = v.w;
-    }
-    const float num = fmaxf(cnt, 1.f);                                                      // kpconv_blocks.py:410-411
-    for (int o = 4 * k; o < Cout; o += 64) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int kk = 0; kk < KP_PAD - 1; kk++) {
-            const float4 wv = *(const float4*)(w_s + kk * Cout + o);
-            a.x = fmaf(wf[kk], wv.x, a.x); a.y = fmaf(wf[kk], wv.y, a.y); a.z = fmaf(wf[kk], wv.z, a.z); a.w = fmaf(wf[kk], wv.w, a.w);
-        }
-        *(float4*)(out + (size_t)q * Cout + o) = make_float4(a.x / num, a.y / num, a.z / num, a.w / num);   // :401-412
-    }
-}
-
 // out[q, c] = max_h x_pad[nbr[q, h], c]   with a zero shadow row   (kpconv_blocks.py:127-143)
 // QW queries per wave: C / 4 lanes (one float4 each) serve a query when C <= 128, so that no lane idles on narrow rows
 template <int QW>
@@ -610,24 +537,6 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     if (LQ == 16) k_kpconv_gather<16><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else if (LQ == 32) k_kpconv_gather<32><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else k_kpconv_gather<64><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
-    RG_RETURN_IF_LAUNCH_FAILED();
-    return RG_OK;
-}
-
-// KPConv.forward for Cin == 1 (the first encoder block), gather and kernel-point contraction fused:
-// out [nq, Cout] = (sum_k WF[q, k] * weights[k, :]) / max(1, #positive neighbours), weights [KP, Cout], Cout % 4 == 0.
-int regtr_kpconv_c1_fused(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                          const float* kernel_points, int KP, float extent, const float* weights, int Cout, float* out,
-                          void* stream)
-{
-    if (!q_xyz || !s_xyz || !nbr || !x || !kernel_points || !weights || !out || nq < 0 || ns < 0 || H < 1 || KP < 1 ||
-        KP >= KP_PAD || !(extent > 0.f) || Cout < 4 || Cout % 4 || ((uintptr_t)out % 16))
-        return RG_ERR_ARG;
-    if (nq == 0) return RG_OK;
-    GatherArgs g{q_xyz, s_xyz, nbr, x, nullptr, kernel_points, nullptr, nullptr, nullptr, nullptr, nq, ns, H, 1, KP, 0, extent, 0.f};
-    const size_t lds = ((size_t)KP_PAD * Cout + GATHER_WAVES * 4 * KP_PAD + (size_t)GATHER_WAVES * 4 * H * 5) * sizeof(float);
-    if (lds > 160 * 1024) return RG_ERR_ARG;
-    k_kpconv_c1_fused<<<rg_cdiv(nq, GATHER_WAVES * 4), GATHER_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(g, weights, Cout, out);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

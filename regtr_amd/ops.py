@@ -164,14 +164,6 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     KP = kernel_points.shape[0]
     dev = x.device
     n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
-    if Cin == 1 and x_stats is None and (w_flat.N if isinstance(w_flat, SplitWeight) else w_flat.shape[1]) % 4 == 0:
-        # first encoder block: gather + contraction in one kernel (no [Nq, 15] intermediate, no K = 15 GEMM); not one of
-        # the gather launches bench.py's roofline times (gather_records)
-        w_kn = w_flat.kn if isinstance(w_flat, SplitWeight) else w_flat
-        out = torch.empty((nq, w_kn.shape[1]), dtype=torch.float32, device=dev)
-        check(L.regtr_kpconv_c1_fused(ptr(q_xyz), nq, ptr(s_xyz), ns, ptr(nbr), H, ptr(x), ptr(kernel_points), KP, float(extent),
-                                      ptr(w_kn), w_kn.shape[1], ptr(out), stream()), 'regtr_kpconv_c1_fused')
-        return (out, instnorm_stats(out, want_stats[0], want_stats[1])) if want_stats is not None else out
     flag = None
     if not L.regtr_kpconv_gather_computes_flag(Cin, H):      # otherwise the gather derives the flags from the rows it reads
         flag = torch.empty(ns, dtype=torch.float32, device=dev)
