@@ -97,11 +97,16 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 
     constexpr int AV = BM * BK / 1024, BV = BK * BN / 1024, KV = BK / 4, NV = BN / 4;
     int row_seg[AV];
+    int seg_first = 0, seg_last = 0;      // (wave-parallel lookups; only tiles straddling clouds search per row)
+    if (g.a_stats) {
+        seg_first = rg_find_segment_wave(g.a_seg_off, g.n_seg, m0);
+        seg_last = rg_find_segment_wave(g.a_seg_off, g.n_seg, min(m0 + BM, g.M) - 1);
+    }
 #pragma unroll
     for (int i = 0; i < AV; i++) {
         row_seg[i] = 0;
         const int row = m0 + (t + i * 256) / KV;
-        if (g.a_stats && row < g.M) row_seg[i] = rg_find_segment(g.a_seg_off, g.n_seg, row);
+        if (g.a_stats && row < g.M) row_seg[i] = seg_first == seg_last ? seg_first : rg_find_segment(g.a_seg_off, g.n_seg, row);
     }
 
     floatx16 acc;

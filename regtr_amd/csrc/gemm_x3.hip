@@ -103,6 +103,25 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     const float* a_ptr[AV];
     const float2* st_ptr[AV];
     bool a_ok[AV];
+    // clouds of the tile's first / last row, found by the whole wave in one round trip each; almost every tile lies inside
+    // one cloud, and only rows of a straddling tile pay the per-lane binary search (log2(n) dependent loads)
+    // The epilogue's cloud range (SOUT) is looked up here too, so that its round trips overlap the first operand loads
+    // instead of being a serial tail: on the short-K GEMMs the per-workgroup chain of dependent memory round trips, not
+    // bandwidth or MFMA, sets the time.
+    int seg_first = 0, seg_last = 0, s_lo = 0, s_hi = 0, s_lo_begin = 0, s_lo_end = 0;
+    const int row_last = min(m0 + BM, g.M) - 1;
+    if (SOUT) {
+        s_lo = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, m0);
+        s_hi = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, row_last);
+        s_lo_begin = g.stat_seg_off[s_lo]; s_lo_end = g.stat_seg_off[s_lo + 1];
+    }
+    if (STATS) {
+        if (SOUT && g.a_seg_off == g.stat_seg_off && g.n_seg == g.n_stat_seg) { seg_first = s_lo; seg_last = s_hi; }
+        else {
+            seg_first = rg_find_segment_wave(g.a_seg_off, g.n_seg, m0);
+            seg_last = rg_find_segment_wave(g.a_seg_off, g.n_seg, row_last);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < AV; i++) {
         const int row = m0 + a_row + RPP * i;
@@ -110,7 +129,10 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
         const int rc = a_ok[i] ? row : g.M - 1;
         a_ptr[i] = g.A + (size_t)rc * g.lda;
         st_ptr[i] = nullptr;
-        if (STATS) st_ptr[i] = g.a_stats + (size_t)rg_find_segment(g.a_seg_off, g.n_seg, rc) * g.K;
+        if (STATS) {
+            const int sg = seg_first == seg_last ? seg_first : rg_find_segment(g.a_seg_off, g.n_seg, rc);
+            st_ptr[i] = g.a_stats + (size_t)sg * g.K;
+        }
     }
     const unsigned a_st_off = (unsigned)a_row * XROW + ((((unsigned)a_k4 >> 3) ^ (((unsigned)a_row >> 2) & 3u)) * 16u) + ((unsigned)t & 1u) * 8u;
     // load_a only ISSUES loads (raw values, nothing consumed): with loads and DMA in flight hipcc waits vmcnt(0) at the
@@ -272,11 +294,9 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     // statistics kernel.
     if (SOUT) {
         double2* red = (double2*)As;                       // [MW][BN], As is free after the last barrier of the k loop
-        const int row_last = min(m0 + BM, g.M) - 1;
-        const int s_lo = rg_find_segment(g.stat_seg_off, g.n_stat_seg, m0);
-        const int s_hi = rg_find_segment(g.stat_seg_off, g.n_stat_seg, row_last);
-        for (int sg = s_lo; sg <= s_hi; sg++) {            // workgroup-uniform
-            const int r_lo = g.stat_seg_off[sg], r_hi = min(g.stat_seg_off[sg + 1], g.M);
+        for (int sg = s_lo; sg <= s_hi; sg++) {            // workgroup-uniform; one cloud per tile almost always
+            const int r_lo = sg == s_lo ? s_lo_begin : g.stat_seg_off[sg];
+            const int r_hi = min(sg == s_lo ? s_lo_end : g.stat_seg_off[sg + 1], g.M);
 #pragma unroll
             for (int j = 0; j < WN; j++) {
                 double sm = 0.0, sq = 0.0;
