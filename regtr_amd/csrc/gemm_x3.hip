@@ -20,6 +20,9 @@
 // the per-lane SOURCE address).  Per k-tile: the A float4 loads and the B DMA of tile t+1 are issued, then the 48 MFMAs
 // per wave of tile t run from LDS while they are in flight (B double-buffered, A split + stored after the MFMAs);
 // two workgroups per CU interleave.  Split-K (deterministic two-pass) for small-M / deep-K shapes.
+// (Measured and dropped: persistent workgroups walking several tiles as one k-tile stream, so that a tile's epilogue overlaps
+// the next tile's first loads -- the prefetched operands stay live across the epilogue and every SOUT / STATS variant
+// spilled or lost a third of its occupancy under hipcc.)
 // (Measured and dropped: an all-DMA variant -- raw float32 A tiles in a 3/4-stage LDS ring issued from inline asm with counted
 // vmcnt waits, the split done at fragment time -- ran 5-30 % SLOWER on every RegTR shape: the fragment-time split is
 // repeated by every wave sharing the rows, and these few-hundred-tile problems are bound by tile quantisation and L2
