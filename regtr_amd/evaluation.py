@@ -1,0 +1,114 @@
+"""3DMatch / 3DLoMatch registration recall from `est.log` files, in process and with numpy only.
+
+Restates the Redwood / Predator evaluation protocol the reference runs after its test loop
+(/root/reference/src/benchmark/benchmark_predator.py: read_trajectory :84-118, read_trajectory_info :120-149,
+computeTransformationErr :60-81, evaluate_registration :223-282, benchmark :285-374; called from
+models/generic_reg_model.py:180-186) without pandas / nibabel / torch: `test.py` prints the same table right after the
+poses are gathered.  Quaternions follow nibabel.quaternions.mat2quat's convention (w >= 0), of which only the vector
+part enters the error.
+"""
+import os
+
+import numpy as np
+
+SHORT_NAMES = ['Kitchen', 'Home 1', 'Home 2', 'Hotel 1', 'Hotel 2', 'Hotel 3', 'Study', 'MIT Lab']
+
+
+def read_trajectory(filename, dim=4):
+    """Redwood trajectory file -> (keys (n, 3) str array, traj (n, dim, dim))   (benchmark_predator.py:84-118)."""
+    with open(filename) as f:
+        lines = f.readlines()
+    keys = [[s.strip() for s in ln.split('\t')[0:3]] for ln in lines[0::dim + 1]]
+    traj = [ln.split('\t')[0:dim] for i, ln in enumerate(lines) if i % (dim + 1) != 0]
+    return np.asarray(keys), np.asarray(traj, dtype=np.float64).reshape(-1, dim, dim)
+
+
+def read_trajectory_info(filename, dim=6):
+    """Redwood information file -> (number of fragments, (n, dim, dim) information matrices)   (:120-149)."""
+    with open(filename) as fid:
+        contents = fid.readlines()
+    n_pairs = len(contents) // 7
+    assert len(contents) == 7 * n_pairs
+    info, n_frame = [], 0
+    for i in range(n_pairs):
+        _, _, n_frame = [int(item) for item in contents[i * 7].strip().split()]
+        info.append(np.stack([np.array(item.split(), dtype=np.float64) for item in contents[i * 7 + 1:i * 7 + 7]]))
+    return n_frame, np.asarray(info, dtype=np.float64).reshape(-1, dim, dim)
+
+
+def mat2quat(M):
+    """Rotation matrix -> quaternion (w, x, y, z), w >= 0: eigenvector of the 4x4 K matrix for its largest eigenvalue
+    (Bar-Itzhack), the method and sign convention of nibabel.quaternions.mat2quat."""
+    Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = np.asarray(M, dtype=np.float64).flat
+    K = np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
+                  [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
+                  [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
+                  [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    return -q if q[0] < 0 else q
+
+
+def transformation_error(trans, info):
+    """RMSE proxy of the Redwood protocol: e^T I e / I[0,0] with e = (t, q_xyz)   (:60-81)."""
+    er = np.concatenate([trans[:3, 3], mat2quat(trans[:3, :3])[1:]])
+    return float(er @ info @ er / info[0, 0])
+
+
+def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_info, err2=0.2):
+    """(:223-282) -> precision, recall, flags (0 good / 1 bad / 2 not in gt), per-pair errors."""
+    err2 = err2 ** 2
+    gt_mask = np.zeros((num_fragment, num_fragment), dtype=np.int64)
+    for idx in range(gt_pairs.shape[0]):
+        i, j = int(gt_pairs[idx, 0]), int(gt_pairs[idx, 1])
+        if j - i > 1:                      # only non-consecutive pairs are tested
+            gt_mask[i, j] = idx
+    n_gt = int(np.sum(gt_mask > 0))
+    errors = np.full(result_pairs.shape[0], np.nan)
+    flags, good, n_res = [], 0, 0
+    for idx in range(result_pairs.shape[0]):
+        i, j = int(result_pairs[idx, 0]), int(result_pairs[idx, 1])
+        if gt_mask[i, j] > 0:
+            n_res += 1
+            gt_idx = gt_mask[i, j]
+            p = transformation_error(np.linalg.inv(gt[gt_idx]) @ result[idx], gt_info[gt_idx])
+            errors[idx] = p
+            good += p <= err2
+            flags.append(0 if p <= err2 else 1)
+        else:
+            flags.append(2)
+    precision = good / (n_res if n_res else 1e6)
+    return precision, good / n_gt, flags, errors
+
+
+def rotation_error_deg(R_gt, R_est):
+    tr = np.clip((np.einsum('nji,nji->n', R_gt, R_est) - 1) / 2, -1, 1)       # trace(R_gt^T R_est)
+    return np.degrees(np.arccos(tr))
+
+
+def benchmark(est_folder, gt_folder):
+    """(:285-374) -> (table string, mean recall over scenes).  est_folder/<scene>/est.log vs gt_folder/<scene>/gt.{log,info}."""
+    scenes = sorted(os.listdir(gt_folder))
+    out = 'Scene\t¦ prec.\t¦ rec.\t¦ re\t¦ te\t¦ samples\t¦\n'
+    precision, recall, n_valids, med_re, med_te = [], [], [], [], []
+    for idx, scene in enumerate(scenes):
+        gt_pairs, gt_traj = read_trajectory(os.path.join(gt_folder, scene, 'gt.log'))
+        n_valid = int(sum(abs(int(e[0]) - int(e[1])) > 1 for e in gt_pairs))
+        n_fragments, gt_info = read_trajectory_info(os.path.join(gt_folder, scene, 'gt.info'))
+        est_pairs, est_traj = read_trajectory(os.path.join(est_folder, scene, 'est.log'))
+        p, r, flags, _ = evaluate_registration(n_fragments, est_traj, est_pairs, gt_pairs, gt_traj, gt_info)
+        # ground truth of every estimated pair (extract_corresponding_trajectors :152-171)
+        lut = {(a, b): k for k, (a, b, _) in enumerate(gt_pairs)}
+        ext = np.stack([gt_traj[lut[(a, b)]] if (a, b) in lut else np.zeros((4, 4)) for a, b, _ in est_pairs])
+        ok = np.asarray(flags) == 0
+        re = rotation_error_deg(ext[:, :3, :3], est_traj[:, :3, :3])[ok]
+        te = np.linalg.norm(ext[:, :3, 3] - est_traj[:, :3, 3], axis=1)[ok]
+        precision.append(p); recall.append(r); n_valids.append(n_valid)
+        med_re.append(np.median(re) if len(re) else np.nan); med_te.append(np.median(te) if len(te) else np.nan)
+        name = SHORT_NAMES[idx] if idx < len(SHORT_NAMES) else scene
+        out += '{}\t¦ {:.3f}\t¦ {:.3f}\t¦ {:.3f}\t¦ {:.3f}\t¦ {:3d}¦\n'.format(name, p, r, med_re[-1], med_te[-1], n_valid)
+    out += 'Mean precision: {:.3f}: +- {:.3f}\n'.format(np.mean(precision), np.std(precision))
+    out += 'Weighted precision: {:.3f}\n'.format((np.array(n_valids) * np.array(precision)).sum() / np.sum(n_valids))
+    out += 'Mean median RRE: {:.3f}: +- {:.3f}\n'.format(np.nanmean(med_re), np.nanstd(med_re))
+    out += 'Mean median RTE: {:.3F}: +- {:.3f}\n'.format(np.nanmean(med_te), np.nanstd(med_te))
+    return out, float(np.mean(recall))

@@ -8,7 +8,8 @@ Runs the MI355X-native RegTR inference path over the benchmark's pairs and write
 (3DMatch / 3DLoMatch) or `<log>/pred_transforms.npy` (ModelNet / ModelLoNet) in the reference's formats
 (models/generic_reg_model.py:194-195, 260-281), which the reference's evaluation scripts read unchanged.
 Inference only: no loss, no tensorboard.  Extra flags: --batch (pairs per forward), --data_root, --synthetic N
-(N deterministic synthetic pairs instead of the dataset files), --max_pairs.
+(N deterministic synthetic pairs instead of the dataset files), --max_pairs, --benchmark_dir (gt.log / gt.info folder: the
+Predator registration-recall table of benchmark/benchmark_predator.py is then printed, computed in process).
 """
 import argparse
 import logging
@@ -38,6 +39,8 @@ parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.r
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
 parser.add_argument('--max_pairs', type=int, default=None)
+parser.add_argument('--benchmark_dir', type=str, default=os.path.join('datasets', '3dmatch', 'benchmarks'),
+                    help='folder with <benchmark>/<scene>/gt.log, gt.info for the registration-recall table')
 
 
 def prepare_logger(opt, rank):
@@ -138,6 +141,13 @@ def main():
         if cfg.dataset == '3dmatch':
             harness.write_est_log(opt.log_path, opt.benchmark, recs)
             logger.info(f'est.log files written under {os.path.join(opt.log_path, opt.benchmark)}')
+            gt_folder = os.path.join(opt.benchmark_dir, opt.benchmark)
+            if opt.synthetic == 0 and os.path.isdir(gt_folder):
+                # Evaluate 3DMatch registration recall (generic_reg_model.py:180-186), in process
+                from regtr_amd.evaluation import benchmark
+                results_str, mean_recall = benchmark(os.path.join(opt.log_path, opt.benchmark), gt_folder)
+                logger.info('\n' + results_str)
+                logger.info(f'Mean registration recall: {mean_recall:.4f}')
         else:
             np.save(os.path.join(opt.log_path, 'pred_transforms.npy'), poses[:, None])    # (n, 1, 3, 4) like torch.stack of (B=1,3,4)
         rot, trans = harness.pose_errors(poses, np.stack(gts))
