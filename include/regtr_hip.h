@@ -132,6 +132,9 @@ int regtr_gemm_x3_stat_tile_rows(int M, int N, int K);
 int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int n_clouds, int C, int tile_rows, float eps,
                                   float* stats, void* stream);
 
+/* out = a + b over n floats (16-byte aligned pointers): with_pos_embed of the post-norm layer, transformers.py:118-119 */
+int regtr_add_f32(const float* a, const float* b, size_t n, float* out, void* stream);
+
 int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
                     float* y, float* y_plain, void* stream);
 

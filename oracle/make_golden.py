@@ -5,6 +5,7 @@ Cases
   modelnet_demo   : data/modelnet_demo_data/modelnet_test_2_{0,1}.ply, conf/modelnet.yaml
   3dmatch_crop    : 1.2 m radius crops of the red-kitchen pair (cloud_bin_0/5), conf/3dmatch.yaml
   3dmatch_kitchen : the full red-kitchen pair (18 977 + 19 084 pts), conf/3dmatch.yaml
+  modelnet_postnorm : the ModelNet pair with pre_norm: False (forward_post), sa_val_has_pos_emb: False
 Each file holds the float32 inputs, the reference module's outputs (reference row order) with
 weights = oracle.seeded_weights.seeded_state_dict(cfg, seed=0), and the reference C++'s
 per-level points / stack lengths.  `native_*` files hold raw outputs of the reference C++ ops.
@@ -39,8 +40,10 @@ def load_pth(path):
     return np.asarray(torch.load(path, weights_only=False))[:, :3].astype(np.float32)
 
 
-def run_case(name, cfg_name, src, tgt, with_feats=False):
+def run_case(name, cfg_name, src, tgt, with_feats=False, overrides=None):
     cfg = ref_loader.load_cfg(cfg_name)
+    for k, v in (overrides or {}).items():
+        cfg[k] = v
     model = ref_loader.build_model(cfg, 0)
     sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
     ref_sd = model.state_dict()
@@ -100,6 +103,9 @@ def main():
     run_case('modelnet_demo', 'modelnet', m0, m1)
     run_case('3dmatch_crop', '3dmatch', c0, c5, with_feats=True)
     run_case('3dmatch_kitchen', '3dmatch', k0, k5)
+    # config variant: post-norm encoder layers (forward_post, transformers.py:121-181), values do not carry the pos-emb
+    run_case('modelnet_postnorm', 'modelnet', m0, m1, overrides={'pre_norm': False, 'sa_val_has_pos_emb': False,
+                                                                  'ca_val_has_pos_emb': True})
 
 
 if __name__ == '__main__':

@@ -228,16 +228,44 @@ def cross_encoder_layer_pre(sd, p, src, tgt, src_pe, tgt_pe, nhead, sa_val_pe=Tr
     return ffn(src), ffn(tgt)
 
 
+def cross_encoder_layer_post(sd, p, src, tgt, src_pe, tgt_pe, nhead, sa_val_pe=True, ca_val_pe=True):
+    """TransformerCrossEncoderLayer.forward_post for one pair (transformers.py:121-181)."""
+    def ln(x, name):
+        return F.layer_norm(x, (x.shape[-1],), sd[p + name + '.weight'], sd[p + name + '.bias'])
+
+    def attn(name, q, k, v):
+        return mha(q, k, v, sd[p + name + '.in_proj_weight'], sd[p + name + '.in_proj_bias'],
+                   sd[p + name + '.out_proj.weight'], sd[p + name + '.out_proj.bias'], nhead)
+
+    sp = src + src_pe                                                      # :131-139
+    src = ln(src + attn('self_attn', sp, sp, sp if sa_val_pe else src), 'norm1')
+    tp = tgt + tgt_pe                                                      # :141-148
+    tgt = ln(tgt + attn('self_attn', tp, tp, tp if sa_val_pe else tgt), 'norm1')
+    sp, tp = src + src_pe, tgt + tgt_pe                                    # :151-152
+    s2 = attn('multihead_attn', sp, tp, tp if ca_val_pe else tgt)          # :154-158
+    t2 = attn('multihead_attn', tp, sp, sp if ca_val_pe else src)          # :159-163
+    src, tgt = ln(src + s2, 'norm2'), ln(tgt + t2, 'norm2')                # :165-166
+
+    def ffn(x):
+        x2 = F.relu(x @ sd[p + 'linear1.weight'].t() + sd[p + 'linear1.bias'])
+        return ln(x + (x2 @ sd[p + 'linear2.weight'].t() + sd[p + 'linear2.bias']), 'norm3')   # :169-175
+    return ffn(src), ffn(tgt)
+
+
 def transformer(sd, cfg, src, tgt, src_pe, tgt_pe, prefix='transformer_encoder.'):
     """TransformerCrossEncoder.forward with return_intermediate and final norm
     (transformers.py:27-59) -> (L, Ns, D), (L, Nt, D)."""
     so, to = [], []
+    layer = cross_encoder_layer_pre if cfg['pre_norm'] else cross_encoder_layer_post     # transformers.py:255-258
     for l in range(cfg['num_encoder_layers']):
-        src, tgt = cross_encoder_layer_pre(sd, f'{prefix}layers.{l}.', src, tgt, src_pe, tgt_pe, cfg['nhead'],
-                                           cfg['sa_val_has_pos_emb'], cfg['ca_val_has_pos_emb'])
-        nw, nb = sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias']
-        so.append(F.layer_norm(src, (src.shape[-1],), nw, nb))
-        to.append(F.layer_norm(tgt, (tgt.shape[-1],), nw, nb))
+        src, tgt = layer(sd, f'{prefix}layers.{l}.', src, tgt, src_pe, tgt_pe, cfg['nhead'],
+                         cfg['sa_val_has_pos_emb'], cfg['ca_val_has_pos_emb'])
+        if prefix + 'norm.weight' in sd:                                                  # encoder norm only with pre_norm (regtr.py:60)
+            nw, nb = sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias']
+            so.append(F.layer_norm(src, (src.shape[-1],), nw, nb))
+            to.append(F.layer_norm(tgt, (tgt.shape[-1],), nw, nb))
+        else:
+            so.append(src); to.append(tgt)
     return torch.stack(so), torch.stack(to)
 
 

@@ -53,8 +53,9 @@ def param_shapes(cfg):
         shapes[p + 'linear2.weight'] = (D, FF); shapes[p + 'linear2.bias'] = (D,)
         for n in ('norm1', 'norm2', 'norm3'):
             shapes[p + n + '.weight'] = (D,); shapes[p + n + '.bias'] = (D,)
-    shapes['transformer_encoder.norm.weight'] = (D,)
-    shapes['transformer_encoder.norm.bias'] = (D,)
+    if cfg['pre_norm']:                                          # encoder_norm only with pre_norm (regtr.py:60)
+        shapes['transformer_encoder.norm.weight'] = (D,)
+        shapes['transformer_encoder.norm.bias'] = (D,)
     q = 'correspondence_decoder.'
     shapes[q + 'coor_mlp.0.weight'] = (D, D); shapes[q + 'coor_mlp.0.bias'] = (D,)
     shapes[q + 'coor_mlp.2.weight'] = (D, D); shapes[q + 'coor_mlp.2.bias'] = (D,)

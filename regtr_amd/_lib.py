@@ -43,6 +43,7 @@ SIGNATURES = {
     'regtr_gemm_x3': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P, _P, _I, _P]),
     'regtr_gemm_x3_stat_tile_rows': (_I, [_I, _I, _I]),
     'regtr_instnorm_finalize_tiles': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
+    'regtr_add_f32': (_I, [_P, _P, _Z, _P, _P]),
     'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),

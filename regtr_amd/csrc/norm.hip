@@ -265,7 +265,28 @@ int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int m
     return RG_OK;
 }
 
+// out = a + b (float4 body, scalar tail): with_pos_embed of the post-norm encoder layer (transformers.py:118-119,131,142)
+__global__ void __launch_bounds__(256) k_add(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ out)
+{
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 x = *(const float4*)(a + i), y = *(const float4*)(b + i);
+        *(float4*)(out + i) = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+    } else {
+        for (size_t j = i; j < n; j++) out[j] = a[j] + b[j];
+    }
+}
+
 // y = LayerNorm(x) * gamma + beta (+ add) ; y_plain (optional) receives the value before `add`.
+int regtr_add_f32(const float* a, const float* b, size_t n, float* out, void* stream)
+{
+    if (!a || !b || !out || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16)) return RG_ERR_ARG;
+    if (n == 0) return RG_OK;
+    k_add<<<rg_cdiv((long long)((n + 3) / 4), 256), 256, 0, (hipStream_t)stream>>>(a, b, n, out);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
 int regtr_layernorm(const float* x, int n, int D, const float* gamma, const float* beta, float eps, const float* add,
                     float* y, float* y_plain, void* stream)
 {

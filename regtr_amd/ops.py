@@ -136,6 +136,14 @@ def layernorm(x, gamma, beta, add=None, eps=1e-5, want_plain=False, out=None):
     return (y, yp) if want_plain else y
 
 
+def add(a, b):
+    """a + b, same shape, contiguous float32 (with_pos_embed of the post-norm encoder layer)."""
+    assert a.shape == b.shape
+    out = torch.empty_like(a)
+    check(_lib.lib().regtr_add_f32(ptr(a), ptr(b), a.numel(), ptr(out), stream()), 'regtr_add_f32')
+    return out
+
+
 def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
     """PositionEmbeddingCoordsSine.forward (position_embedding.py:29-50).  The 84-entry frequency table is
     init-time constant data computed exactly the way the reference computes it (float32 pow)."""

@@ -23,8 +23,6 @@ class TransformerCrossEncoderLayer(nn.Module):
             raise NotImplementedError                                             # transformers.py:94-98
         if activation != 'relu':
             raise NotImplementedError('only the ReLU feed-forward of the shipped configs is implemented')
-        if not normalize_before:
-            raise NotImplementedError('forward_post (pre_norm: False) is not implemented; both shipped configs use pre_norm')
         if dropout != 0.0:
             raise NotImplementedError('inference path: dropout must be 0 (as in both shipped configs)')
         # parameter containers with the reference's names; their torch forward is never called
@@ -35,7 +33,7 @@ class TransformerCrossEncoderLayer(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.norm2 = nn.LayerNorm(d_model)
         self.norm3 = nn.LayerNorm(d_model)
-        self.nhead, self.d_model = nhead, d_model
+        self.nhead, self.d_model, self.normalize_before = nhead, d_model, normalize_before
         self.sa_val_has_pos_emb, self.ca_val_has_pos_emb = sa_val_has_pos_emb, ca_val_has_pos_emb
         self._cache = {}
 
@@ -64,8 +62,36 @@ class TransformerCrossEncoderLayer(nn.Module):
         att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
         return ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
 
+    def _attention_post(self, attn, tag, x, norm, pe, val_has_pe, seg_off, kv_of, max_len):
+        """LN( x + out_proj( MHA(q = k = x + pe, v = x [+ pe]) ) ) for every token (forward_post, transformers.py:131-166)."""
+        D = self.d_model
+        b_in = attn.in_proj_bias.detach()
+        xp = x if pe is None else ops.add(x, pe)
+        if pe is None or val_has_pe:
+            qkv = ops.gemm(xp, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
+        else:
+            qkv = torch.empty((x.shape[0], 3 * D), dtype=torch.float32, device=x.device)
+            b_qk = _prepared(self._cache, tag + '_bqk', attn.in_proj_bias, lambda b: b[:2 * D].contiguous())
+            b_v = _prepared(self._cache, tag + '_bv', attn.in_proj_bias, lambda b: b[2 * D:].contiguous())
+            ops.gemm(xp, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
+            ops.gemm(x, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
+        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
+        y = ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
+        return ops.layernorm(y, norm.weight.detach(), norm.bias.detach(), eps=norm.eps)
+
+    def forward_post(self, x, pe, seg_off, kv_self, kv_cross, max_len):
+        """transformers.py:121-181 on packed tokens: both cross-attention directions read the post-norm1 values."""
+        x = self._attention_post(self.self_attn, 'sa', x, self.norm1, pe, self.sa_val_has_pos_emb, seg_off, kv_self, max_len)
+        x = self._attention_post(self.multihead_attn, 'ca', x, self.norm2, pe, self.ca_val_has_pos_emb, seg_off, kv_cross,
+                                 max_len)
+        h = ops.gemm(x, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
+        y = ops.gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)       # :168-170
+        return ops.layernorm(y, self.norm3.weight.detach(), self.norm3.bias.detach(), eps=self.norm3.eps)
+
     def forward(self, x, pe, seg_off, kv_self, kv_cross, max_len):
         """x: (N_total, D) tokens of all clouds [src_0..src_{B-1}, tgt_0..tgt_{B-1}]."""
+        if not self.normalize_before:                                              # transformers.py:255-258
+            return self.forward_post(x, pe, seg_off, kv_self, kv_cross, max_len)
         x = self._attention(self.self_attn, 'sa', x, self.norm1, pe, self.sa_val_has_pos_emb, seg_off, kv_self, max_len)
         x = self._attention(self.multihead_attn, 'ca', x, self.norm2, pe, self.ca_val_has_pos_emb, seg_off, kv_cross,
                             max_len)

@@ -61,6 +61,20 @@ def test_forward_vs_oracle_small(case, cfgn):
           float(np.abs(out['pose'].cpu().numpy() - g['pose']).max()))
 
 
+def test_forward_post_norm_variant():
+    """pre_norm: False (TransformerCrossEncoderLayer.forward_post, transformers.py:121-181; no encoder norm) with values
+    that do not carry the positional embedding in self-attention: product vs oracle (the oracle is pinned to the real
+    reference module on this very configuration, tests/golden/modelnet_postnorm.npz)."""
+    g = gold('modelnet_postnorm')
+    cfg = load_cfg('modelnet')
+    cfg.update({'pre_norm': False, 'sa_val_has_pos_emb': False, 'ca_val_has_pos_emb': True})
+    sd = seeded_sd(cfg)
+    assert 'transformer_encoder.norm.weight' not in sd
+    out, _ = _run_product(cfg, sd, [g['src']], [g['tgt']])
+    ref = _run_oracle(cfg, sd, [g['src']], [g['tgt']])
+    _compare(out, ref, 1, 1e-4)
+
+
 def test_forward_kitchen_full_size():
     """BASELINE config[2]: the real 3DMatch red-kitchen pair (18 977 + 19 084 points)."""
     g = gold('3dmatch_kitchen')

@@ -63,13 +63,19 @@ def test_native_vs_unmodified_reference_cpp():
     assert np.array_equal(ordered, idx)
 
 
-@pytest.mark.parametrize('case,cfgn', [('modelnet_demo', 'modelnet'), ('3dmatch_crop', '3dmatch')])
-def test_float_restatement_vs_reference_golden(case, cfgn):
-    """oracle/regtr_ref.py driven in the REFERENCE's row order reproduces the reference module's outputs."""
+POSTNORM = {'pre_norm': False, 'sa_val_has_pos_emb': False, 'ca_val_has_pos_emb': True}    # oracle/make_golden.py
+
+
+@pytest.mark.parametrize('case,cfgn,overrides', [('modelnet_demo', 'modelnet', {}), ('3dmatch_crop', '3dmatch', {}),
+                                                 ('modelnet_postnorm', 'modelnet', POSTNORM)])
+def test_float_restatement_vs_reference_golden(case, cfgn, overrides):
+    """oracle/regtr_ref.py driven in the REFERENCE's row order reproduces the reference module's outputs
+    (pre-norm layers of both shipped configs, and the post-norm forward_post variant)."""
     if not native.have_ref():
         pytest.skip('needs oracle/_ref for the reference row order')
     g = gold(case)
     cfg = load_cfg(cfgn)
+    cfg.update(overrides)
     sd = seeded_sd(cfg)
     with torch.no_grad():
         out = regtr_ref.regtr_forward(sd, cfg, [g['src']], [g['tgt']], use_ref_cpp=True)
