@@ -75,6 +75,36 @@ def main():
                         flags=np.array([out[s][2] for s in texts], dtype=object), errors=np.array([out[s][3] for s in texts], dtype=object),
                         table=np.array(table), mean_recall=mean_recall)
     print(table, mean_recall)
+    modelnet_golden()
+
+
+def modelnet_golden():
+    """benchmark/benchmark_modelnet.py compute_metrics + summarize_metrics of the reference on seeded random inputs."""
+    import torch
+    sys.path.insert(0, ROOT)
+    from oracle import ref_loader
+    ref_loader.load()                                   # mocks for the absent optional dependencies (cvhelpers, ...)
+    import cvhelpers.torch_helpers as th
+    th.to_numpy = lambda x: x.detach().cpu().numpy() if hasattr(x, 'detach') else np.asarray(x)
+    import importlib
+    bm = importlib.import_module('benchmark.benchmark_modelnet')
+    bm.to_numpy = th.to_numpy
+    rng = np.random.default_rng(7)
+    B, N = 4, 300
+    raw = rng.uniform(-1, 1, (B, N, 3)).astype(np.float32)
+    gt = np.stack([_pose(rng, 45, 0.5)[:3] for _ in range(B)]).astype(np.float32)
+    pred = np.stack([(np.vstack([g, [0, 0, 0, 1]]) @ _pose(rng, 4, 0.03))[:3] for g in gt]).astype(np.float32)
+    ref = raw[:, :220] + rng.normal(scale=0.01, size=(B, 220, 3)).astype(np.float32)
+    Rg, tg = gt[:, :, :3], gt[:, :, 3]
+    src = (np.einsum('bij,bnj->bni', np.transpose(Rg, (0, 2, 1)), raw[:, 80:] - tg[:, None]) +
+           rng.normal(scale=0.01, size=(B, N - 80, 3))).astype(np.float32)       # inverse gt applied: src -> ref under gt
+    data = {'transform_gt': torch.from_numpy(gt), 'points_src': torch.from_numpy(src), 'points_ref': torch.from_numpy(ref),
+            'points_raw': torch.from_numpy(raw)}
+    m = bm.compute_metrics(data, torch.from_numpy(pred))
+    sm = bm.summarize_metrics(m)
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'modelnet_metrics.npz'), gt=gt, pred=pred, src=src, ref=ref, raw=raw,
+                        **{'m_' + k: np.asarray(v) for k, v in m.items()}, **{'s_' + k: np.asarray(v) for k, v in sm.items()})
+    print({k: float(v) for k, v in sm.items()})
 
 
 if __name__ == '__main__':

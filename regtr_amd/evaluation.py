@@ -112,3 +112,51 @@ def benchmark(est_folder, gt_folder):
     out += 'Mean median RRE: {:.3f}: +- {:.3f}\n'.format(np.nanmean(med_re), np.nanstd(med_re))
     out += 'Mean median RTE: {:.3F}: +- {:.3f}\n'.format(np.nanmean(med_te), np.nanstd(med_te))
     return out, float(np.mean(recall))
+
+
+# ------------------------------------------------------------------------------------------------------ ModelNet metrics
+def modelnet_metrics(pred, gt, points_src, points_ref, points_raw):
+    """benchmark/benchmark_modelnet.py:33-90 (compute_metrics, RPMNet / DCP conventions) in numpy.
+    pred, gt (B, 3, 4); points_* (B, N, >=3).  Returns the per-instance metric arrays of the reference."""
+    from scipy.spatial import cKDTree
+    from scipy.spatial.transform import Rotation
+    pred, gt = np.asarray(pred, np.float64), np.asarray(gt, np.float64)
+    src, ref, raw = (np.asarray(p, np.float64)[..., :3] for p in (points_src, points_ref, points_raw))
+    e_gt = Rotation.from_matrix(gt[:, :3, :3]).as_euler('xyz', degrees=True)
+    e_pr = Rotation.from_matrix(pred[:, :3, :3]).as_euler('xyz', degrees=True)
+    t_gt, t_pr = gt[:, :3, 3], pred[:, :3, 3]
+
+    def cat(a, b):        # a o b  (se3_torch.se3_cat)
+        return np.concatenate([a[:, :, :3] @ b[:, :, :3], a[:, :, :3] @ b[:, :, 3:] + a[:, :, 3:]], axis=2)
+
+    def inv(a):
+        Rt = np.swapaxes(a[:, :, :3], 1, 2)
+        return np.concatenate([Rt, -Rt @ a[:, :, 3:]], axis=2)
+
+    def apply(a, p):
+        return p @ np.swapaxes(a[:, :, :3], 1, 2) + a[:, None, :, 3]
+
+    c = cat(inv(gt), pred)
+    err_r = np.degrees(np.arccos(np.clip(0.5 * (np.trace(c[:, :, :3], axis1=1, axis2=2) - 1), -1, 1)))
+    err_t = np.linalg.norm(c[:, :, 3], axis=1)
+    src_t = apply(pred, src)
+    src_clean = apply(cat(pred, inv(gt)), raw)
+    chamfer = np.array([np.mean(cKDTree(raw[b]).query(src_t[b])[0] ** 2) + np.mean(cKDTree(src_clean[b]).query(ref[b])[0] ** 2)
+                        for b in range(len(pred))])
+    return {'r_mse': np.mean((e_gt - e_pr) ** 2, axis=1), 'r_mae': np.mean(np.abs(e_gt - e_pr), axis=1),
+            't_mse': np.mean((t_gt - t_pr) ** 2, axis=1), 't_mae': np.mean(np.abs(t_gt - t_pr), axis=1),
+            'err_r_deg': err_r, 'err_t': err_t, 'chamfer_dist': chamfer}
+
+
+def summarize_metrics(metrics):
+    """benchmark_modelnet.py:93-105."""
+    out = {}
+    for k, v in metrics.items():
+        if k.endswith('mse'):
+            out[k[:-3] + 'rmse'] = np.sqrt(np.mean(v))
+        elif k.startswith('err'):
+            out[k + '_mean'] = np.mean(v)
+            out[k + '_rmse'] = np.sqrt(np.mean(v ** 2))
+        else:
+            out[k] = np.mean(v)
+    return out

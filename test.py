@@ -150,6 +150,17 @@ def main():
                 logger.info(f'Mean registration recall: {mean_recall:.4f}')
         else:
             np.save(os.path.join(opt.log_path, 'pred_transforms.npy'), poses[:, None])    # (n, 1, 3, 4) like torch.stack of (B=1,3,4)
+            # RPMNet / DCP metrics (benchmark_modelnet.py:33-105); the clean cloud of a synthetic pair is its own target
+            from regtr_amd.evaluation import modelnet_metrics, summarize_metrics
+            items = [pairs[int(i)] for i in ids]
+            per = [modelnet_metrics(poses[k:k + 1], np.stack(gts)[k:k + 1], it['src_xyz'][None], it['tgt_xyz'][None], it['tgt_xyz'][None])
+                   for k, it in enumerate(items)]
+            sm = summarize_metrics({key: np.concatenate([p[key] for p in per]) for key in per[0]})
+            logger.info('DeepCP metrics:{:.4f}(rot-rmse) | {:.4f}(rot-mae) | {:.4g}(trans-rmse) | {:.4g}(trans-mae)'.format(
+                sm['r_rmse'], sm['r_mae'], sm['t_rmse'], sm['t_mae']))
+            logger.info('Rotation error {:.4f}(deg, mean) | {:.4f}(deg, rmse)'.format(sm['err_r_deg_mean'], sm['err_r_deg_rmse']))
+            logger.info('Translation error {:.4g}(mean) | {:.4g}(rmse)'.format(sm['err_t_mean'], sm['err_t_rmse']))
+            logger.info('Chamfer error: {:.7f}(mean-sq)'.format(sm['chamfer_dist']))
         rot, trans = harness.pose_errors(poses, np.stack(gts))
         ok = np.logical_and(rot < cfg.get('reg_success_thresh_rot', 10), trans < cfg.get('reg_success_thresh_trans', 0.1))
         logger.info(f'[Metrics] rot_err_deg_final: {rot.mean():.4f}, trans_err_final: {trans.mean():.4f}, reg_success_final: {ok.mean():.4f} '

@@ -38,3 +38,15 @@ def test_est_log_roundtrip_through_evaluation(tmp_path):
     keys, traj = ev.read_trajectory(str(tmp_path / '3DMatch' / 'sc' / 'est.log'))
     assert keys.tolist() == [['0', '1', '-1'], ['2', '3', '-1'], ['4', '5', '-1']]
     assert np.allclose(traj[:, :3, :], poses, atol=1e-11) and np.allclose(traj[:, 3], [0, 0, 0, 1])
+
+
+def test_modelnet_metrics_match_reference():
+    """benchmark_modelnet.compute_metrics / summarize_metrics of the reference (golden, float32 torch) vs the numpy restatement."""
+    from regtr_amd import evaluation as ev
+    from tests.util import GOLD
+    g = np.load(os.path.join(GOLD, 'modelnet_metrics.npz'))
+    m = ev.modelnet_metrics(g['pred'], g['gt'], g['src'], g['ref'], g['raw'])
+    for k, v in m.items():
+        assert np.allclose(v, g['m_' + k], rtol=2e-4, atol=2e-6), (k, v, g['m_' + k])
+    for k, v in ev.summarize_metrics(m).items():
+        assert np.allclose(v, g['s_' + k], rtol=2e-4, atol=2e-6), k
