@@ -111,3 +111,18 @@ def test_cli_demo_py(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     o = np.load(tmp_path / 'o.npz')
     assert o['pose'].shape == (3, 4) and np.isfinite(o['pose']).all() and o['src2tgt'].shape == o['src_kp'].shape
+
+
+@pytest.mark.gpu
+def test_cli_test_py_synthetic_modelnet(tmp_path):
+    """ModelNet branch of test.py: pred_transforms.npy in the reference's (n, 1, 3, 4) layout + the DCP / RPMNet metric lines."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'test.py'), '--benchmark', 'ModelNet', '--config',
+                        os.path.join(ROOT, 'regtr_amd', 'conf', 'modelnet.yaml'), '--logdir', str(tmp_path / 'logs'),
+                        '--synthetic', '3', '--batch', '2'], cwd=tmp_path, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    run = os.listdir(tmp_path / 'logs')[0]
+    poses = np.load(tmp_path / 'logs' / run / 'pred_transforms.npy')
+    assert poses.shape == (3, 1, 3, 4) and np.isfinite(poses).all()
+    log = open(tmp_path / 'logs' / run / 'log.txt').read()
+    assert 'DeepCP metrics:' in log and 'Chamfer error:' in log
