@@ -3,15 +3,19 @@
 //   /root/reference/src/models/backbone_kpconv/kpconv_blocks.py:269-414, max_pool :127-143.
 //
 // The reference materialises (Nq,H,15,3) differences, (Nq,H,15) influences and (Nq,H,Cin) gathered features as
-// separate tensors.  Here one pass per query tile does everything on chip:
-//   phase 1  lanes = neighbours: coalesced read of the index row, gather of the neighbour xyz, centred offsets and
-//            the "feature sum > 0" flags into LDS;
-//   phase 2  lanes = (neighbour, kernel point): 15 linear influences max(0, 1 - |y - kp_k| / extent) into an
-//            LDS-staged [H][16] tile (each lane keeps its kernel point in registers);
-//   phase 3  lanes = channels: the neighbour feature rows are gathered once (row-contiguous, line-sized reads),
-//            influences are broadcast from LDS as 128-bit reads and 15 accumulators per channel stay in registers.
-// Output is the weighted-feature matrix WF[q][k*Cin + c] that feeds the MFMA contraction with the [15*Cin, Cout]
-// kernel weights (gemm.hip), plus the reference's data-dependent normaliser
+// separate tensors; here they never exist.  Three kernels, chosen by the launcher from Cin:
+//   k_kpconv_gather_mfma<J,V>  Cin a multiple of 32 (every block of both shipped configs but the first): the per-query
+//                              correlation runs on the f32 matrix cores, see the comment above the kernel;
+//   k_kpconv_gather_c1         Cin == 1 (first block, features = ones): lanes = (query, kernel point);
+//   k_kpconv_gather<LQ>        any other Cin -- the general LDS-tile form:
+//     phase 1  lanes = neighbours: coalesced read of the index row, gather of the neighbour xyz, centred offsets and the
+//              "feature sum > 0" flags into LDS;
+//     phase 2  lanes = (neighbour, kernel point): 15 linear influences max(0, 1 - |y - kp_k| / extent) into an LDS-staged
+//              [H][16] tile (each lane keeps its kernel point in registers);
+//     phase 3  lanes = channels: the neighbour feature rows are gathered once (row-contiguous, line-sized reads),
+//              influences are broadcast from LDS as 128-bit reads and 15 accumulators per channel stay in registers.
+// Output is the weighted-feature matrix WF[q][k*Cin + c] that feeds the kernel-point contraction with the
+// [15*Cin, Cout] weights (gemm_x3.hip / gemm.hip), plus the reference's data-dependent normaliser
 //   num[q] = max(1, #{h : sum_c x[n_qh, c] > 0})            kpconv_blocks.py:409-411
 // which the GEMM epilogue divides by.
 #include "common.h"

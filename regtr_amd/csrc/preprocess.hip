@@ -158,17 +158,6 @@ __device__ __forceinline__ int hash_insert(int* __restrict__ rep, unsigned mask,
     }
 }
 
-__device__ __forceinline__ int hash_find(const int* __restrict__ rep, unsigned mask, const uint64_t* __restrict__ tkey,
-                                         const int* __restrict__ tcid, uint64_t key, int cid)
-{
-    unsigned h = rg_hash64(key ^ ((uint64_t)(cid + 1) * 0x9E3779B97F4A7C15ULL)) & mask;
-    for (;;) {
-        if (rep[h] < 0) return -1;
-        if (tkey[h] == key && tcid[h] == cid) return (int)h;
-        h = (h + 1) & mask;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // grid subsample
 // ------------------------------------------------------------------------------------------------
@@ -454,11 +443,6 @@ __device__ __forceinline__ void slot_find(const CellSlot* __restrict__ slots, un
 
 struct GridView {
     const CellSlot* slots;
-    const int* rep;
-    const uint64_t* tkey;
-    const int* tcid;
-    const uint64_t* cell_start;
-    const int* cnt;
     const float4* sorted;
     double inv_cs;
 };
@@ -719,7 +703,7 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     if (nq_cap <= 0) return RG_OK;
     hipStream_t st = (hipStream_t)stream;
     GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap > 0 ? ns_cap : 1);
-    GridView g{b.slots, b.rep, b.tkey, b.tcid, b.cell_start, b.cnt, b.sorted, 1.0 / ((double)radius * (1.0 + 1e-6))};
+    GridView g{b.slots, b.sorted, 1.0 / ((double)radius * (1.0 + 1e-6))};
     // LDS list capacity per query: room for the K survivors of a shrink plus one 64-candidate round
     int cap = (2 * K + 63) / 64 * 64;
     if (cap < 256) cap = 256;
