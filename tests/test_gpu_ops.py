@@ -260,7 +260,8 @@ def test_cpp_wrappers_dropin():
 
 
 # ------------------------------------------------------------------------------------------------ encoder kernels
-@pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40)])
+@pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40),
+                                        (16, 64, 40), (48, 32, 40), (20, 12, 33)])      # last three: general LDS-tile gather + flag pass
 def test_kpconv_vs_oracle(Cin, Cout, H):
     from oracle import native, regtr_ref
     from regtr_amd.kernel_points import K015_CENTER
