@@ -29,6 +29,7 @@
  *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
  *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
  *   regtr_mha_fwd             nn.MultiheadAttention core          transformers.py:197-226
+ *   regtr_attn_xyz            CorrespondenceDecoder.simple_attention   models/regtr.py:316-351
  *   regtr_weighted_procrustes pose assembly + compute_rigid_transform   regtr.py:185-203, utils/se3_torch.py:108-154
  */
 #ifndef REGTR_HIP_H
@@ -146,6 +147,12 @@ int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
                   void* stream);
+
+/* CorrespondenceDecoder.simple_attention (regtr.py:316-351, `direct_regress_coor: False`): single-head attention whose values
+ * are coordinates.  q, k [n_layers, n_total, head_dim] contiguous (projections of the conditioned features), xyz [n_total,3],
+ * out [n_layers, n_total, 3]; cloud c attends cloud kv_of[c]; head_dim in {32, 64, 128, 256}. */
+int regtr_attn_xyz(const float* q, const float* k, const float* xyz, float* out, const int* seg_off, const int* kv_of,
+                   int n_clouds, int n_total, int n_layers, int max_len, int head_dim, float scale, void* stream);
 
 /* kp [n_total,3], corr [L,n_total,3], logit [L,n_total], seg_off [2*n_pairs+1] -> pose [L,n_pairs,3,4] */
 int regtr_weighted_procrustes(const float* kp, const float* corr, const float* logit, const int* seg_off, int n_pairs,

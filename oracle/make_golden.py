@@ -6,6 +6,7 @@ Cases
   3dmatch_crop    : 1.2 m radius crops of the red-kitchen pair (cloud_bin_0/5), conf/3dmatch.yaml
   3dmatch_kitchen : the full red-kitchen pair (18 977 + 19 084 pts), conf/3dmatch.yaml
   modelnet_postnorm : the ModelNet pair with pre_norm: False (forward_post), sa_val_has_pos_emb: False
+  modelnet_attn_head : the ModelNet pair with direct_regress_coor: False (attention CorrespondenceDecoder)
 Each file holds the float32 inputs, the reference module's outputs (reference row order) with
 weights = oracle.seeded_weights.seeded_state_dict(cfg, seed=0), and the reference C++'s
 per-level points / stack lengths.  `native_*` files hold raw outputs of the reference C++ ops.
@@ -106,6 +107,8 @@ def main():
     # config variant: post-norm encoder layers (forward_post, transformers.py:121-181), values do not carry the pos-emb
     run_case('modelnet_postnorm', 'modelnet', m0, m1, overrides={'pre_norm': False, 'sa_val_has_pos_emb': False,
                                                                   'ca_val_has_pos_emb': True})
+    # config variant: attention CorrespondenceDecoder instead of the MLP head (regtr.py:299-396)
+    run_case('modelnet_attn_head', 'modelnet', m0, m1, overrides={'direct_regress_coor': False})
 
 
 if __name__ == '__main__':

@@ -278,6 +278,20 @@ def correspondence_regressor(sd, f, prefix='correspondence_decoder.'):
     return corr, logit
 
 
+def correspondence_decoder_attn(sd, sc, tc, s_xyz, t_xyz, s_pe, t_pe, use_pe, prefix='correspondence_decoder.'):
+    """CorrespondenceDecoder.forward / simple_attention for one pair (regtr.py:316-396): sc, tc (L, N, D)."""
+    D = sc.shape[-1]
+
+    def attend(qf, kf, xyz):
+        q = (qf @ sd[prefix + 'q_proj.weight'].t() + sd[prefix + 'q_proj.bias']) / math.sqrt(D)          # :329
+        k = kf @ sd[prefix + 'k_proj.weight'].t() + sd[prefix + 'k_proj.bias']                           # :330
+        return torch.softmax(q @ k.transpose(-1, -2), dim=-1) @ xyz                                      # :332-347
+    s2, t2 = (sc + s_pe, tc + t_pe) if use_pe else (sc, tc)                                              # :372-373
+    s_corr, t_corr = attend(s2, t2, t_xyz), attend(t2, s2, s_xyz)                                        # :374-377
+    w, b = sd[prefix + 'conf_logits_decoder.weight'], sd[prefix + 'conf_logits_decoder.bias']
+    return s_corr, sc @ w.t() + b, t_corr, tc @ w.t() + b                                                # :379-380
+
+
 def compute_rigid_transform(a, b, weights):
     """utils/se3_torch.py:108-154 (weighted Kabsch)."""
     wn = weights[..., None] / torch.clamp_min(weights.sum(-1, keepdim=True)[..., None], 1e-6)
@@ -324,8 +338,12 @@ def regtr_forward(sd, cfg, src_list, tgt_list, meta=None, use_ref_cpp=False, tim
         spe = pe_l[b] if cfg['transformer_encoder_has_pos_emb'] else zero
         tpe = pe_l[B + b] if cfg['transformer_encoder_has_pos_emb'] else zero
         sc, tc = transformer(sd, cfg, s, t, spe, tpe)                       # regtr.py:160-166
-        s_corr, s_logit = correspondence_regressor(sd, sc)                  # :168
-        t_corr, t_logit = correspondence_regressor(sd, tc)
+        if cfg.get('direct_regress_coor', False):
+            s_corr, s_logit = correspondence_regressor(sd, sc)              # :168
+            t_corr, t_logit = correspondence_regressor(sd, tc)
+        else:
+            s_corr, s_logit, t_corr, t_logit = correspondence_decoder_attn(sd, sc, tc, xyz_l[b], xyz_l[B + b], pe_l[b], pe_l[B + b],
+                                                                            cfg['corr_decoder_has_pos_emb'])
         L = sc.shape[0]
         a = torch.cat([xyz_l[b].expand(L, -1, -1), t_corr], 1)              # :187-190
         bb = torch.cat([s_corr, xyz_l[B + b].expand(L, -1, -1)], 1)

@@ -57,9 +57,14 @@ def param_shapes(cfg):
         shapes['transformer_encoder.norm.weight'] = (D,)
         shapes['transformer_encoder.norm.bias'] = (D,)
     q = 'correspondence_decoder.'
-    shapes[q + 'coor_mlp.0.weight'] = (D, D); shapes[q + 'coor_mlp.0.bias'] = (D,)
-    shapes[q + 'coor_mlp.2.weight'] = (D, D); shapes[q + 'coor_mlp.2.bias'] = (D,)
-    shapes[q + 'coor_mlp.4.weight'] = (3, D); shapes[q + 'coor_mlp.4.bias'] = (3,)
+    if cfg.get('direct_regress_coor', False):                    # CorrespondenceRegressor (regtr.py:399-443)
+        shapes[q + 'coor_mlp.0.weight'] = (D, D); shapes[q + 'coor_mlp.0.bias'] = (D,)
+        shapes[q + 'coor_mlp.2.weight'] = (D, D); shapes[q + 'coor_mlp.2.bias'] = (D,)
+        shapes[q + 'coor_mlp.4.weight'] = (3, D); shapes[q + 'coor_mlp.4.bias'] = (3,)
+    else:                                                        # CorrespondenceDecoder (regtr.py:299-314)
+        shapes[q + 'q_norm.weight'] = (D,); shapes[q + 'q_norm.bias'] = (D,)
+        shapes[q + 'q_proj.weight'] = (D, D); shapes[q + 'q_proj.bias'] = (D,)
+        shapes[q + 'k_proj.weight'] = (D, D); shapes[q + 'k_proj.bias'] = (D,)
     shapes[q + 'conf_logits_decoder.weight'] = (1, D); shapes[q + 'conf_logits_decoder.bias'] = (1,)
     if cfg.get('feature_loss_type', 'infonce') == 'infonce':     # feature_loss.py:261 (training-only params)
         shapes['feature_criterion.W'] = (D, D)

@@ -47,6 +47,7 @@ SIGNATURES = {
     'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _P]),
+    'regtr_attn_xyz': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
 }
 

@@ -138,6 +138,108 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Single-head dot-product attention whose VALUES are coordinates: CorrespondenceDecoder.simple_attention
+// (/root/reference/src/models/regtr.py:316-351, the `direct_regress_coor: False` head).  out[l, q, :] =
+// softmax_s( Q[l, q, :] . K[l, s, :] * scale ) @ xyz[s, :]  over the keys s of the partner cloud kv_of[cloud(q)], for every
+// decoder layer l; Q / K are (L, N, HD) row-major projections of the conditioned features, xyz (N, 3) is shared by the layers.
+// Same flash-style structure as k_mha_fwd (S^T = K Q^T with one query column per lane, P^T fed back as the B operand of
+// O^T += V^T P^T); the head dimension is a template parameter and V^T has 3 live rows.  A rarely used configuration:
+// written for correctness, K tiles are staged without prefetch.
+// ------------------------------------------------------------------------------------------------------------------
+struct AttnXyzArgs {
+    const float* q; const float* k; const float* xyz; float* out;
+    const int* seg_off; const int* kv_of;
+    int n_total;
+    float scale;
+};
+
+template <int HDX>
+__global__ void __launch_bounds__(RG_WAVE) k_attn_xyz(AttnXyzArgs g)
+{
+    constexpr int KS = HDX + 1;                       // odd row stride: conflict-free fragment reads
+    extern __shared__ float smem_x[];
+    float* Ks = smem_x;                               // [TK][HDX + 1]
+    float* Vs = smem_x + TK * KS;                     // [TK][LDS_STRIDE], columns >= 3 are zero
+    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    const int cloud = blockIdx.z, layer = blockIdx.y;
+    const int q_begin = g.seg_off[cloud], q_end = g.seg_off[cloud + 1];
+    const int q0 = q_begin + blockIdx.x * TQ;
+    if (q0 >= q_end) return;
+    const int kc = g.kv_of[cloud];
+    const int k_begin = g.seg_off[kc], nk = g.seg_off[kc + 1] - k_begin;
+    const float* Q = g.q + (size_t)layer * g.n_total * HDX;
+    const float* K = g.k + (size_t)layer * g.n_total * HDX;
+
+    float qreg[HDX / 2];                              // B operand of S^T = K Q^T: Q[q0 + l31][2 s + hi] * scale
+    {
+        const int qrow = q0 + l31;
+        const bool live = qrow < q_end;
+#pragma unroll
+        for (int s = 0; s < HDX / 2; s++) qreg[s] = live ? Q[(size_t)qrow * HDX + 2 * s + hi] * g.scale : 0.f;
+    }
+    floatx16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int kt = 0; kt < nk; kt += TK) {
+        __syncthreads();
+        for (int row = 0; row < TK; row++) {          // one key row (HDX floats) per pass: 64 lanes x 4 floats
+            const bool live = kt + row < nk;
+            for (int c4 = lane * 4; c4 < HDX; c4 += RG_WAVE * 4) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) v = *(const float4*)(K + (size_t)(k_begin + kt + row) * HDX + c4);
+                float* kd = &Ks[row * KS + c4];
+                kd[0] = v.x; kd[1] = v.y; kd[2] = v.z; kd[3] = v.w;
+            }
+        }
+        for (int e = lane; e < TK * LDS_STRIDE; e += RG_WAVE) {
+            const int row = e / LDS_STRIDE, d = e - row * LDS_STRIDE;
+            Vs[e] = (d < 3 && kt + row < nk) ? g.xyz[(size_t)(k_begin + kt + row) * 3 + d] : 0.f;
+        }
+        __syncthreads();
+
+        floatx16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < HDX / 2; s++)
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[l31 * KS + 2 * s + hi], qreg[s], sc, 0, 0, 0);
+
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (kt + acc_row(r, hi) >= nk) sc[r] = -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, RG_WAVE));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            sc[r] = expf(sc[r] - m_new);
+            psum += sc[r];
+        }
+        psum += __shfl_xor(psum, 32, RG_WAVE);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[acc_row(s, hi) * LDS_STRIDE + l31], sc[s], o, 0, 0, 0);
+    }
+    // O^T rows 0..2 = x, y, z live in registers 0..2 of the lower half-wave (acc_row(r, 0) = r for r < 4)
+    const int qrow = q0 + l31;
+    if (qrow < q_end && hi == 0) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        float* dst = g.out + ((size_t)layer * g.n_total + qrow) * 3;
+        dst[0] = o[0] * inv; dst[1] = o[1] * inv; dst[2] = o[2] * inv;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -155,6 +257,29 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
     if (max_len == 0) return RG_OK;
     MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
     k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, (hipStream_t)stream>>>(g);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// CorrespondenceDecoder.simple_attention (regtr.py:316-351): q, k (n_layers, n_total, head_dim) contiguous, xyz (n_total, 3),
+// out (n_layers, n_total, 3); cloud c attends the keys / coordinates of cloud kv_of[c].  head_dim in {32, 64, 128, 256}.
+int regtr_attn_xyz(const float* q, const float* k, const float* xyz, float* out, const int* seg_off, const int* kv_of,
+                   int n_clouds, int n_total, int n_layers, int max_len, int head_dim, float scale, void* stream)
+{
+    if (!q || !k || !xyz || !out || !seg_off || !kv_of || n_clouds < 1 || n_total < 0 || n_layers < 1 || max_len < 0)
+        return RG_ERR_ARG;
+    if ((((uintptr_t)q | (uintptr_t)k) % 16)) return RG_ERR_ARG;
+    if (max_len == 0 || n_total == 0) return RG_OK;
+    AttnXyzArgs g{q, k, xyz, out, seg_off, kv_of, n_total, scale};
+    const dim3 grid(rg_cdiv(max_len, TQ), n_layers, n_clouds);
+    hipStream_t st = (hipStream_t)stream;
+#define RG_ATTN_XYZ(HDX_) k_attn_xyz<HDX_><<<grid, RG_WAVE, (TK * (HDX_ + 1) + TK * LDS_STRIDE) * sizeof(float), st>>>(g)
+    if (head_dim == 256) RG_ATTN_XYZ(256);
+    else if (head_dim == 128) RG_ATTN_XYZ(128);
+    else if (head_dim == 64) RG_ATTN_XYZ(64);
+    else if (head_dim == 32) RG_ATTN_XYZ(32);
+    else return RG_ERR_ARG;
+#undef RG_ATTN_XYZ
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

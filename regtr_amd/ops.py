@@ -243,6 +243,15 @@ def mha(q, k, v, seg_off, kv_of, max_len, n_heads):
     return out
 
 
+def attn_xyz(q, k, xyz, seg_off, kv_of, max_len):
+    """CorrespondenceDecoder.simple_attention: q, k (L, N, D) contiguous, xyz (N, 3) -> (L, N, 3)."""
+    Lyr, N, D = q.shape
+    out = torch.empty((Lyr, N, 3), dtype=torch.float32, device=q.device)
+    check(_lib.lib().regtr_attn_xyz(ptr(q), ptr(k), ptr(xyz), ptr(out), ptr(seg_off), ptr(kv_of), seg_off.numel() - 1, N, Lyr,
+                                    int(max_len), D, 1.0 / math.sqrt(D), stream()), 'regtr_attn_xyz')
+    return out
+
+
 def weighted_procrustes(kp, corr, logit, seg_off, n_pairs):
     """kp (N,3), corr (L,N,3), logit (L,N), seg_off (2B+1,) i32 -> pose (L,B,3,4)."""
     Lyr, N = logit.shape

@@ -59,6 +59,34 @@ class CorrespondenceRegressor(nn.Module):
         return corr.view(Lyr, N, 3), logit.view(Lyr, N)
 
 
+class CorrespondenceDecoder(nn.Module):
+    """regtr.py:299-396 (`direct_regress_coor: False`): correspondences as attention-weighted partner coordinates --
+    softmax(q_proj(f [+ pe]) . k_proj(f_partner [+ pe]) / sqrt(D)) @ xyz_partner per decoder layer -- and the overlap logit.
+    `q_norm` is a parameter of the reference module that its forward never uses; it is kept for strict loading."""
+
+    def __init__(self, d_embed, use_pos_emb, num_neighbors=0):
+        super().__init__()
+        if num_neighbors != 0:
+            raise NotImplementedError('num_neighbors > 0 (top-k masked attention) is not used by the reference model')
+        self.use_pos_emb = use_pos_emb
+        self.q_norm = nn.LayerNorm(d_embed)
+        self.q_proj = nn.Linear(d_embed, d_embed)
+        self.k_proj = nn.Linear(d_embed, d_embed)
+        self.conf_logits_decoder = nn.Linear(d_embed, 1)
+        self._cache = {}
+
+    def forward(self, feats, pe, xyz, seg_off, kv_cross, max_len):
+        """feats (L, N, D) conditioned features of all clouds, pe (N, D), xyz (N, 3) -> corr (L, N, 3), logit (L, N)."""
+        Lyr, N, D = feats.shape
+        wt = lambda k, lin: _prepared(self._cache, k, lin.weight, lambda w: ops.SplitWeight(w, 'nk'))
+        f2 = torch.stack([ops.add(feats[l], pe) for l in range(Lyr)]) if self.use_pos_emb else feats       # :372-373
+        q = ops.gemm(f2.view(Lyr * N, D), wt('q', self.q_proj), bias=self.q_proj.bias.detach())
+        k = ops.gemm(f2.view(Lyr * N, D), wt('k', self.k_proj), bias=self.k_proj.bias.detach())
+        corr = ops.attn_xyz(q.view(Lyr, N, D), k.view(Lyr, N, D), xyz, seg_off, kv_cross, max_len)         # :374-377
+        logit = ops.gemm(feats.reshape(Lyr * N, D), wt('c', self.conf_logits_decoder), bias=self.conf_logits_decoder.bias.detach())
+        return corr, logit.view(Lyr, N)
+
+
 class _LossParams(nn.Module):
     """Holds InfoNCELossFull.W (feature_loss.py:261) so reference checkpoints load strictly; never used at inference."""
 
@@ -90,8 +118,7 @@ class RegTR(nn.Module):
         if cfg.get('direct_regress_coor', False):                                 # :68-73
             self.correspondence_decoder = CorrespondenceRegressor(cfg.d_embed)
         else:
-            raise NotImplementedError('the attention CorrespondenceDecoder (direct_regress_coor: False) is not implemented; '
-                                      'both shipped configs regress coordinates with the MLP head')
+            self.correspondence_decoder = CorrespondenceDecoder(cfg.d_embed, cfg.corr_decoder_has_pos_emb)
         if cfg.get('feature_loss_type', 'infonce') == 'infonce':                  # :79-81
             self.feature_criterion = _LossParams(cfg.d_embed)
             self.feature_criterion_un = _LossParams(cfg.d_embed)
@@ -136,7 +163,11 @@ class RegTR(nn.Module):
         feats_cond = self.transformer_encoder(both_feats_un, pe, seg_c, kv_self, kv_cross, max(slens_c))   # (L, N, D)
 
         # ---- correspondence head (regtr.py:168) and pose (regtr.py:185-203)
-        corr, logit = self.correspondence_decoder(feats_cond)
+        if isinstance(self.correspondence_decoder, CorrespondenceRegressor):
+            corr, logit = self.correspondence_decoder(feats_cond)
+        else:
+            pe_c = pe if pe is not None else self.pos_embed(xyz_c)
+            corr, logit = self.correspondence_decoder(feats_cond, pe_c, xyz_c, seg_c, kv_cross, max(slens_c))
         if ev: ev[3].record()
         pose = ops.weighted_procrustes(xyz_c, corr, logit, seg_c, B)
         if ev:

@@ -75,6 +75,25 @@ def test_forward_post_norm_variant():
     _compare(out, ref, 1, 1e-4)
 
 
+def test_forward_attention_head_variant():
+    """direct_regress_coor: False (CorrespondenceDecoder.simple_attention, regtr.py:299-396): product vs oracle; the oracle is
+    pinned to the real reference module on this configuration (tests/golden/modelnet_attn_head.npz)."""
+    g = gold('modelnet_attn_head')
+    cfg = load_cfg('modelnet')
+    cfg.update({'direct_regress_coor': False})
+    sd = seeded_sd(cfg)
+    assert 'correspondence_decoder.q_proj.weight' in sd and 'correspondence_decoder.coor_mlp.0.weight' not in sd
+    out, _ = _run_product(cfg, sd, [g['src']], [g['tgt']])
+    ref = _run_oracle(cfg, sd, [g['src']], [g['tgt']])
+    _compare(out, ref, 1, 1e-4)
+    # and a ragged batch of two pairs == the pairs one at a time
+    s2, t2 = g['tgt'][:500], g['src'][:640]
+    both, _ = _run_product(cfg, sd, [g['src'], s2], [g['tgt'], t2])
+    one, _ = _run_product(cfg, sd, [s2], [t2])
+    assert (both['src_kp_warped'][1] - one['src_kp_warped'][0]).abs().max() < 1e-5
+    assert (both['src_kp_warped'][0] - out['src_kp_warped'][0]).abs().max() < 1e-5
+
+
 def test_forward_kitchen_full_size():
     """BASELINE config[2]: the real 3DMatch red-kitchen pair (18 977 + 19 084 points)."""
     g = gold('3dmatch_kitchen')

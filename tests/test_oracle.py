@@ -67,10 +67,11 @@ POSTNORM = {'pre_norm': False, 'sa_val_has_pos_emb': False, 'ca_val_has_pos_emb'
 
 
 @pytest.mark.parametrize('case,cfgn,overrides', [('modelnet_demo', 'modelnet', {}), ('3dmatch_crop', '3dmatch', {}),
-                                                 ('modelnet_postnorm', 'modelnet', POSTNORM)])
+                                                 ('modelnet_postnorm', 'modelnet', POSTNORM),
+                                                 ('modelnet_attn_head', 'modelnet', {'direct_regress_coor': False})])
 def test_float_restatement_vs_reference_golden(case, cfgn, overrides):
     """oracle/regtr_ref.py driven in the REFERENCE's row order reproduces the reference module's outputs
-    (pre-norm layers of both shipped configs, and the post-norm forward_post variant)."""
+    (pre-norm layers of both shipped configs, the post-norm forward_post variant, the attention CorrespondenceDecoder)."""
     if not native.have_ref():
         pytest.skip('needs oracle/_ref for the reference row order')
     g = gold(case)
