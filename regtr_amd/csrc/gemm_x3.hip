@@ -6,7 +6,8 @@
 //     a * w  =  a0 w0 + (a0 w1 + a1 w0) + (a0 w2 + a1 w1 + a2 w0)  +  O(2^-24 |a w|)
 // and the GEMM is six v_mfma_f32_32x32x16_bf16 per (32 x 32 x 16) block with f32 accumulation -- float32-grade results
 // (the dropped terms are below one f32 ulp of each product) at up to 16/6 of the f32-MFMA rate.  Terms are issued
-// smallest first.  Serves the same call sites as gemm.hip (kpconv_blocks.py:401-406,557; regtr.py:145,432-436;
+// smallest first.  (Finite inputs only: an infinite operand splits into Inf + NaN, so it yields NaN where the exact-f32 kernel
+// yields Inf; a NaN stays a NaN.)  Serves the same call sites as gemm.hip (kpconv_blocks.py:401-406,557; regtr.py:145,432-436;
 // transformers.py:197-238) whenever N is a multiple of 64; thin / odd shapes stay on the exact-f32 kernel.
 //
 // Weights are split ONCE (regtr_gemm_split_weights) into three bf16 planes of W^T, Wt[p][n][k] (k contiguous, K padded
