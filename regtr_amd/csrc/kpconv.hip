@@ -187,7 +187,10 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
 // pass over x (and no flag gather) is needed.
 // ------------------------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-constexpr int MG_QPW = 8;      // queries handled one after another by each wave
+#ifndef RG_MG_QPW
+#define RG_MG_QPW 8
+#endif
+constexpr int MG_QPW = RG_MG_QPW;      // queries handled one after another by each wave
 
 template <int V> struct RgVec;
 template <> struct RgVec<2> { typedef float2 type; };
