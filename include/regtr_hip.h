@@ -56,6 +56,13 @@ size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds);
 int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
                          int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
 
+/* The same with a choice of output row order: row_order 0 = first appearance (above); 1 = the reference's own order, i.e.
+ * the iteration order of the libstdc++ std::unordered_map<size_t, .> it fills in input order (grid_subsampling.cpp:48,58-59,85)
+ * -- the parity mode (cfg.kpconv_ref_row_order); one thread per cloud replays the container (csrc/ref_order.h). */
+size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_order);
+int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order,
+                                 float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
+
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds);
 
 /* Builds the support-point cell grid for `radius` into ws (kept by the caller, reused by any number of queries). */
@@ -69,6 +76,26 @@ int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds,
 int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
                        int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
                        int* out_count, int* out_max_count, void* stream);
+
+/* Parity mode (cfg.kpconv_ref_row_order): the same neighbour sets in the REFERENCE's row order -- nanoflann's KD-tree
+ * visiting order passed through std::sort on the distance alone (neighbors.cpp:246-267, nanoflann.hpp:857-1003,1348-1412,
+ * 1285-1287) -- so that rows truncated to K keep the very supports the reference keeps when distances tie.  One thread
+ * builds the tree of one cloud, one thread answers one query (csrc/ref_order.h); a parity tool, not a throughput path.
+ *   regtr_kdtree_build          tree of every cloud into ws (regtr_kdtree_ws_bytes)
+ *   regtr_kdtree_radius_query   out_idx [nq_cap,K] (first K of each row, pad = Ns_total), out_count / out_max_count as in
+ *                               regtr_radius_query; list_cap >= the largest in-ball count (rows with more are cut at
+ *                               list_cap BEFORE sorting -- the caller re-runs with list_cap = *out_max_count);
+ *                               scratch: regtr_kdtree_query_scratch_bytes(list_cap).
+ *                               out_status (optional device int, zeroed by the caller): set to 1 if a query overflowed its
+ *                               traversal stack (96 pending subtrees; rows then invalid). */
+size_t regtr_kdtree_ws_bytes(int ns_cap, int n_clouds);
+size_t regtr_kdtree_query_scratch_bytes(int list_cap);
+int regtr_kdtree_build(const float* s_xyz, const int* s_seg_off, int n_clouds, int ns_cap, void* ws, size_t ws_bytes,
+                       void* stream);
+int regtr_kdtree_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const float* s_xyz,
+                              const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, int list_cap,
+                              const void* tree_ws, size_t ws_bytes, void* scratch, size_t scratch_bytes, int* out_idx,
+                              int* out_count, int* out_max_count, int* out_status, void* stream);
 
 /* ---- KPConv encoder --------------------------------------------------------------------------------------- */
 
@@ -89,7 +116,10 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
                         void* stream);
 
-int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream);
+/* out[q,:] = max over the first H columns of row q of nbr (row stride ld_nbr >= H) of x[nbr[q,h],:], the shadow index
+ * ns standing for a zero row (kpconv_blocks.py:127-143).  H < ld_nbr serves the reference's CPU tables, whose width is
+ * min(max in-ball count, neighborhood_limit) (kpconv.py:255-258): a full row then holds no shadow and its maximum may be negative. */
+int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream);
 
 size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C);
 int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int max_len, int C, float eps, float* stats,

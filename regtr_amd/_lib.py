@@ -23,13 +23,19 @@ _Z = _c.c_size_t
 SIGNATURES = {
     'regtr_grid_subsample_ws_bytes': (_Z, [_I, _I]),
     'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
+    'regtr_grid_subsample_ordered_ws_bytes': (_Z, [_I, _I, _I]),
+    'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    'regtr_kdtree_ws_bytes': (_Z, [_I, _I]),
+    'regtr_kdtree_query_scratch_bytes': (_Z, [_I]),
+    'regtr_kdtree_build': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
+    'regtr_kdtree_radius_query': (_I, [_P, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _Z, _P, _P, _P, _P, _P]),
     'regtr_cellgrid_ws_bytes': (_Z, [_I, _I]),
     'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
     'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
     'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
-    'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _P, _P]),
+    'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),
     'regtr_instnorm_apply': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P]),
@@ -75,14 +81,68 @@ def check(status, what):
         raise RuntimeError(f'{what}: {_ERR.get(status, "error")} (status {status})')
 
 
-def ptr(t):
-    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous and live on a GPU."""
+_active_device = [None]     # device index the enclosing forward pinned with on_device(); None = ask torch
+
+
+class on_device:
+    """`with on_device(dev):` -- makes `dev` the current HIP device for the enclosed launches (kernels are enqueued on
+    torch's current stream OF THE CURRENT DEVICE, so tensors on cuda:1 under a current device 0 would otherwise be launched
+    on the wrong GPU) and lets ptr() verify every tensor argument lives there."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('regtr_amd ops need GPU tensors (no CPU fallback)')
+        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.ctx = torch.cuda.device(self.index)
+
+    def __enter__(self):
+        self.ctx.__enter__()
+        self.prev = _active_device[0]
+        _active_device[0] = self.index
+        return self
+
+    def __exit__(self, *exc):
+        _active_device[0] = self.prev
+        return self.ctx.__exit__(*exc)
+
+
+def ptr(t, dtype=torch.float32):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous, of the dtype the kernel reads (float32
+    unless stated) and live on the GPU the launch goes to."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError('regtr_amd ops need GPU tensors (no CPU fallback)')
+    if t.dtype != dtype:
+        raise RuntimeError(f'regtr_amd op expected a {dtype} tensor, got {t.dtype} (the kernels reinterpret nothing)')
     if not t.is_contiguous():
         raise RuntimeError('regtr_amd ops need contiguous tensors')
+    dev = _active_device[0]
+    if t.device.index != (dev if dev is not None else torch.cuda.current_device()):
+        raise RuntimeError(f'tensor on {t.device} but the launch device is cuda:{dev if dev is not None else torch.cuda.current_device()}; '
+                           'wrap the call in regtr_amd._lib.on_device(tensor.device)')
+    return t.data_ptr()
+
+
+def iptr(t):
+    return ptr(t, torch.int32)
+
+
+def bptr(t):
+    return ptr(t, torch.uint8)
+
+
+def dptr(t):
+    return ptr(t, torch.float64)
+
+
+def raw(t):
+    """data_ptr of a float32 row-strided view (unit column stride is the caller's business)."""
+    if t is None:
+        return None
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise RuntimeError(f'regtr_amd op expected a float32 GPU tensor, got {t.dtype} on {t.device}')
     return t.data_ptr()
 
 

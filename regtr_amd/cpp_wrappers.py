@@ -6,12 +6,25 @@
         /root/reference/src/models/backbone_kpconv/cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238 (parse :71-75, return :214-227)
 
 numpy in / numpy out like the originals (torch CUDA tensors are also accepted and returned); shape errors raise
-RuntimeError as the originals do.  Row orders are the canonical ones documented in kpconv.py.
+RuntimeError as the originals do.  Row orders are the canonical ones documented in kpconv.py; after
+`cpp_wrappers.reference_order(True)` they are the reference's own (libstdc++ unordered_map iteration order for the
+subsampled rows, nanoflann visiting order + std::sort for the neighbour rows -- the parity mode of kpconv.py), and the
+results equal the originals' element for element.
 """
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
+
+
+_REFERENCE_ORDER = [False]
+
+
+def reference_order(on=True):
+    """Switch both ops to the reference's own row orders (parity mode).  Returns the previous setting."""
+    prev = _REFERENCE_ORDER[0]
+    _REFERENCE_ORDER[0] = bool(on)
+    return prev
 
 
 def _dev():
@@ -43,7 +56,8 @@ class _Subsampling:
         seg, lens = _seg(batches)
         if int(lens.sum()) != pts.shape[0]:
             raise RuntimeError('Wrong number of points : sum(batches) != N')
-        out, out_seg = ops.grid_subsample(pts, seg, pts.shape[0], float(sampleDl))
+        with _lib.on_device(pts.device):
+            out, out_seg = ops.grid_subsample(pts, seg, pts.shape[0], float(sampleDl), row_order=int(_REFERENCE_ORDER[0]))
         oseg = out_seg.cpu().numpy()
         s_len = np.diff(oseg).astype(np.int32)
         if max_p > 0 and (s_len > max_p).any():                                           # grid_subsampling.cpp:181-204
@@ -70,16 +84,22 @@ class _Neighbors:
             raise RuntimeError('Wrong number of batch elements: different for queries and supports')   # :165-171
         if int(qlens.sum()) != q.shape[0] or int(slens.sum()) != s.shape[0]:
             raise RuntimeError('Wrong number of points : sum(batches) != N')
-        grid = ops.CellGrid(s, sseg, s.shape[0], float(radius))
-        K = 64
-        while True:
-            idx, cnt, mx = grid.query(q, qseg, q.shape[0], K, want_count=True)
-            width = int(mx.item())
-            if width <= K or K >= 448:
-                break
-            K = min(448, max(2 * K, width))
-        if width > K:
-            raise RuntimeError(f'batch_query: a ball holds {width} supports, above the kernel limit of 448')
+        with _lib.on_device(q.device):
+            if _REFERENCE_ORDER[0]:
+                tree = ops.KdTree(s, sseg, s.shape[0])
+                _, width = tree.query(q, qseg, q.shape[0], float(radius), 1)          # pass 1: the row width (max in-ball count)
+                idx, _ = tree.query(q, qseg, q.shape[0], float(radius), max(width, 1), list_cap=max(width, 16))
+            else:
+                grid = ops.CellGrid(s, sseg, s.shape[0], float(radius))
+                K = 64
+                while True:
+                    idx, cnt, mx = grid.query(q, qseg, q.shape[0], K, want_count=True)
+                    width = int(mx.item())
+                    if width <= K or K >= 448:
+                        break
+                    K = min(448, max(2 * K, width))
+                if width > K:
+                    raise RuntimeError(f'batch_query: a ball holds {width} supports, above the kernel limit of 448')
         if width == 0:
             raise RuntimeError('Error converting output: no neighbour found')           # wrapper.cpp:201-205
         idx = idx[:q.shape[0], :width].contiguous()

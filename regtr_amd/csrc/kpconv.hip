@@ -458,13 +458,13 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
 // QW queries per wave: C / 4 lanes (one float4 each) serve a query when C <= 128, so that no lane idles on narrow rows
 template <int QW>
 __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
-                                                        int nq, int H, float* __restrict__ out)
+                                                        int ld_nbr, int nq, int H, float* __restrict__ out)
 {
     constexpr int LQ = RG_WAVE / QW;                 // lanes per query
     const int lane = rg_lane();
     const int q = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * QW + lane / LQ;
     if (q >= nq) return;
-    const int* row = nbr + (size_t)q * H;
+    const int* row = nbr + (size_t)q * ld_nbr;
     for (int c = (lane % LQ) * 4; c < C; c += LQ * 4) {
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int h0 = 0; h0 < H; h0 += 8) {
@@ -548,13 +548,13 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     return RG_OK;
 }
 
-int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int nq, int H, float* out, void* stream)
+int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream)
 {
-    if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || C < 4 || C % 4) return RG_ERR_ARG;
+    if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || ld_nbr < H || C < 4 || C % 4) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
-    if (C <= 64) k_maxpool_gather<4><<<rg_cdiv(nq, 16), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, nq, H, out);
-    else if (C <= 128) k_maxpool_gather<2><<<rg_cdiv(nq, 8), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, nq, H, out);
-    else k_maxpool_gather<1><<<rg_cdiv(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, nq, H, out);
+    if (C <= 64) k_maxpool_gather<4><<<rg_cdiv(nq, 16), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+    else if (C <= 128) k_maxpool_gather<2><<<rg_cdiv(nq, 8), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+    else k_maxpool_gather<1><<<rg_cdiv(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

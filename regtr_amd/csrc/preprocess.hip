@@ -19,6 +19,7 @@
 //   Distance and voxel arithmetic use explicit round-to-nearest intrinsics (no FMA contraction) so the
 //   float32 results match the reference's SSE2 arithmetic bit for bit.
 #include "common.h"
+#include "ref_order.h"
 #include <limits.h>
 
 namespace {
@@ -298,7 +299,8 @@ __global__ void __launch_bounds__(256) k_scatter_members(const int* __restrict__
 __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ xyz, const int* __restrict__ n_ptr,
                                                      const int* __restrict__ slot_of, const int* __restrict__ first,
                                                      const int* __restrict__ cnt, const uint64_t* __restrict__ scan_out,
-                                                     int* __restrict__ members, float* __restrict__ out_xyz)
+                                                     int* __restrict__ members, const int* __restrict__ dest,
+                                                     float* __restrict__ out_xyz)
 {
     const int n = *n_ptr;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,7 +308,8 @@ __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ x
     const int s = slot_of[i];
     if (first[s] != i) return;
     const uint64_t so = scan_out[i];
-    const unsigned j = (unsigned)(so >> 32), start = (unsigned)(so & 0xFFFFFFFFu);
+    const unsigned start = (unsigned)(so & 0xFFFFFFFFu);
+    const unsigned j = dest ? (unsigned)dest[so >> 32] : (unsigned)(so >> 32);     // reference row order (parity mode)
     const int c = cnt[s];
     int* m = members + start;
     for (int a = 1; a < c; a++) {  // insertion sort (lists are a handful of points)
@@ -324,6 +327,31 @@ __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ x
     out_xyz[3 * (size_t)j] = __fmul_rn(sx, w);
     out_xyz[3 * (size_t)j + 1] = __fmul_rn(sy, w);
     out_xyz[3 * (size_t)j + 2] = __fmul_rn(sz, w);
+}
+
+// ---- reference row order (parity mode, ref_order.h): the voxel keys in first-appearance order, then one thread per cloud
+// replays the libstdc++ unordered_map the reference iterates (grid_subsampling.cpp:48,58-59,85) ----
+__global__ void __launch_bounds__(256) k_rank_keys(const int* __restrict__ n_ptr, const int* __restrict__ slot_of,
+                                                   const int* __restrict__ first, const uint64_t* __restrict__ scan_out,
+                                                   const uint64_t* __restrict__ pkey, uint64_t* __restrict__ vkey)
+{
+    const int n = *n_ptr;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (first[slot_of[i]] == i) vkey[scan_out[i] >> 32] = pkey[i];
+}
+
+__global__ void k_umap_order(const uint64_t* __restrict__ vkey, const int* __restrict__ out_seg_off, int n_clouds,
+                             int* __restrict__ unext, int* __restrict__ ubefore, int* __restrict__ uorder,
+                             int* __restrict__ dest)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_clouds) return;
+    const int base = out_seg_off[c], m = out_seg_off[c + 1] - base;
+    if (m <= 0) return;
+    int* order = uorder + base;
+    rg_umap_iteration_order(vkey + base, m, unext + base + c, ubefore + rg_umap_before_offset(base, c), order);
+    for (int p = 0; p < m; p++) dest[base + order[p]] = base + p;
 }
 
 __global__ void k_out_offsets(const int* __restrict__ seg_off, int n_clouds, const uint64_t* __restrict__ scan_in,
@@ -591,13 +619,13 @@ GridBuffers carve_grid(void* ws, size_t ws_bytes, int ns_cap)
 }
 
 struct SubsampleBuffers {
-    uint64_t *pkey, *scan_in, *scan_out, *bsum;
-    int *pcid, *slot_of, *members, *rep, *first, *cnt, *fill, *bbox;
+    uint64_t *pkey, *scan_in, *scan_out, *bsum, *vkey;
+    int *pcid, *slot_of, *members, *rep, *first, *cnt, *fill, *bbox, *unext, *ubefore, *uorder, *dest;
     unsigned T;
     size_t bytes;
 };
 
-SubsampleBuffers carve_subsample(void* ws, size_t ws_bytes, int n_cap, int n_clouds)
+SubsampleBuffers carve_subsample(void* ws, size_t ws_bytes, int n_cap, int n_clouds, int row_order)
 {
     SubsampleBuffers b;
     RgCarver c(ws, ws_bytes);
@@ -607,6 +635,14 @@ SubsampleBuffers carve_subsample(void* ws, size_t ws_bytes, int n_cap, int n_clo
     b.rep = c.take<int>(b.T); b.first = c.take<int>(b.T); b.cnt = c.take<int>(b.T); b.fill = c.take<int>(b.T);
     b.bsum = c.take<uint64_t>(rg_cdiv(n_cap, SCAN_TILE) + 1);
     b.bbox = c.take<int>((size_t)n_clouds * 6);
+    b.vkey = nullptr; b.unext = b.ubefore = b.uorder = b.dest = nullptr;
+    if (row_order == 1) {
+        b.vkey = c.take<uint64_t>(n_cap);
+        b.unext = c.take<int>((size_t)n_cap + n_clouds);
+        b.ubefore = c.take<int>(rg_umap_before_offset(n_cap, n_clouds) + 16);
+        b.uorder = c.take<int>(n_cap);
+        b.dest = c.take<int>(n_cap);
+    }
     b.bytes = rg_align_up(c.off, 256);
     return b;
 }
@@ -615,24 +651,26 @@ SubsampleBuffers carve_subsample(void* ws, size_t ws_bytes, int n_cap, int n_clo
 
 extern "C" {
 
-size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds)
+size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_order)
 {
     if (n_cap < 1) n_cap = 1;
     if (n_clouds < 1) n_clouds = 1;
-    return carve_subsample(nullptr, ~(size_t)0, n_cap, n_clouds).bytes + 4096;
+    return carve_subsample(nullptr, ~(size_t)0, n_cap, n_clouds, row_order).bytes + 4096;
 }
+size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds) { return regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, 0); }
 
-int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
-                         int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
+int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order,
+                                 float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!xyz || !seg_off || !out_xyz || !out_seg_off || n_clouds < 1 || n_cap < 0 || !(dl > 0.f)) return RG_ERR_ARG;
-    if (ws_bytes < regtr_grid_subsample_ws_bytes(n_cap, n_clouds)) return RG_ERR_WORKSPACE;
+    if (!xyz || !seg_off || !out_xyz || !out_seg_off || n_clouds < 1 || n_cap < 0 || !(dl > 0.f) || row_order < 0 || row_order > 1)
+        return RG_ERR_ARG;
+    if (ws_bytes < regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, row_order)) return RG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (n_cap == 0) {
         (void)hipMemsetAsync(out_seg_off, 0, sizeof(int) * (n_clouds + 1), st);
         return RG_OK;
     }
-    SubsampleBuffers sb = carve_subsample(ws, ws_bytes, n_cap, n_clouds);
+    SubsampleBuffers sb = carve_subsample(ws, ws_bytes, n_cap, n_clouds, row_order);
     const unsigned T = sb.T;
     uint64_t *pkey = sb.pkey, *scan_in = sb.scan_in, *scan_out = sb.scan_out, *bsum = sb.bsum;
     int *pcid = sb.pcid, *slot_of = sb.slot_of, *members = sb.members, *rep = sb.rep, *first = sb.first,
@@ -648,10 +686,20 @@ int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);
     scan_u64(scan_in, n_ptr, n_cap, bsum, scan_out, st);
     k_scatter_members<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, scan_out, fill, members);
-    k_barycentres<<<nb, 256, 0, st>>>(xyz, n_ptr, slot_of, first, cnt, scan_out, members, out_xyz);
     k_out_offsets<<<rg_cdiv(n_clouds + 1, 64), 64, 0, st>>>(seg_off, n_clouds, scan_in, scan_out, out_seg_off);
+    if (row_order == 1) {
+        k_rank_keys<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, scan_out, pkey, sb.vkey);
+        k_umap_order<<<rg_cdiv(n_clouds, 64), 64, 0, st>>>(sb.vkey, out_seg_off, n_clouds, sb.unext, sb.ubefore, sb.uorder, sb.dest);
+    }
+    k_barycentres<<<nb, 256, 0, st>>>(xyz, n_ptr, slot_of, first, cnt, scan_out, members, sb.dest, out_xyz);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
+}
+
+int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
+                         int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
+{
+    return regtr_grid_subsample_ordered(xyz, seg_off, n_clouds, n_cap, dl, 0, out_xyz, out_seg_off, ws, ws_bytes, stream);
 }
 
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds)

@@ -7,10 +7,18 @@ arithmetic is in libregtr_hip.so.
 
 Semantics are those of the reference's CPU ops (cpp_wrappers): voxel key floor((p - origin) / dl), neighbours
 distance-sorted then truncated to neighborhood_limits.  Documented differences, none of which changes a downstream
-value: neighbour tables always have K = neighborhood_limits[l] columns (the CPU path emits min(max_count, K),
-kpconv.py:255-258; extra columns are shadow indices), exact-distance ties are ordered by support index, subsampled
-rows are in first-appearance order, index tensors are int32 unless cfg.kpconv_meta_int64 is set, and the unused
-`upsamples` tables (kpconv.py:503-504; RegTR has no decoder) are left empty.
+value beyond float rounding and ties: neighbour tables always have K = neighborhood_limits[l] columns like the reference's
+GPU path (kpconv.py:276-283; its CPU path emits min(max_count, K), kpconv.py:255-258 -- the extra columns are shadow
+indices), exact-distance ties are ordered by support index, subsampled rows are in first-appearance order, index tensors
+are int32 unless cfg.kpconv_meta_int64 is set, and the unused `upsamples` tables (kpconv.py:503-504; RegTR has no
+decoder) are left empty.
+
+cfg.kpconv_ref_row_order = True selects the PARITY MODE: every implementation-defined choice of the reference's CPU
+ops is reproduced on the GPU -- subsampled rows in libstdc++ unordered_map iteration order, neighbour rows in nanoflann
+visiting order passed through std::sort (which decides WHICH equidistant supports a truncated row keeps), tables
+min(max_count, K) wide (a full row then has no zero shadow row in max_pool) -- so `kpconv_meta` equals the reference
+`Preprocessor`'s output element for element and the network outputs can be compared with the reference's own at 1e-4
+(tests/test_gpu_model.py).  It costs extra host synchronisations and serial kernels; the default mode stays the fast one.
 """
 from typing import List
 
@@ -47,13 +55,14 @@ class Preprocessor(nn.Module):
         device = pts[0].device
         lens0 = [int(p.shape[0]) for p in pts]
         n0 = sum(lens0)
-        n_clouds = len(pts)
         points = torch.cat([p.to(torch.float32) for p in pts], dim=0).contiguous()
         seg = torch.tensor(np.concatenate([[0], np.cumsum(lens0)]).astype(np.int32), device=device)
+        # parity mode: the reference CPU ops' implementation-defined row orders and table widths (see module docstring)
+        ref_order = bool(cfg.get('kpconv_ref_row_order', False))
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
-        lv_points, lv_seg, lv_conv, lv_pool = [], [], [], []
+        lv_points, lv_seg, lv_conv, lv_pool, lv_width = [], [], [], [], []
         cap = n0                                                              # N_{l+1} <= N_l <= N_0
         arch = cfg.architecture
         for block_i, block in enumerate(arch):                               # kpconv.py:328-404
@@ -66,15 +75,26 @@ class Preprocessor(nn.Module):
             if any('deformable' in b for b in layer_blocks) or 'deformable' in block:
                 raise NotImplementedError('deformable KPConv is outside the RegTR inference path')
             K = limits[layer]
-            grid = ops.CellGrid(points, seg, cap, r_normal)
-            conv_i = grid.query(points, seg, cap, K) if layer_blocks else None           # :349-351
-            if 'pool' in block or 'strided' in block:
-                dl = 2 * r_normal / cfg.conv_radius                                      # :363
-                pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)              # :366
-                pool_i = grid.query(pool_p, pool_seg, cap, K)                            # :376
+            strided = 'pool' in block or 'strided' in block
+            dl = 2 * r_normal / cfg.conv_radius                                          # :363
+            conv_i = pool_p = pool_seg = pool_i = None
+            conv_w = pool_w = K
+            if not ref_order:
+                grid = ops.CellGrid(points, seg, cap, r_normal)
+                if layer_blocks:
+                    conv_i = grid.query(points, seg, cap, K)                             # :349-351
+                if strided:
+                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)          # :366
+                    pool_i = grid.query(pool_p, pool_seg, cap, K)                        # :376
             else:
-                pool_p = pool_seg = pool_i = None
+                tree = ops.KdTree(points, seg, cap)
+                if layer_blocks:
+                    conv_i, conv_w = tree.query(points, seg, cap, r_normal, K)
+                if strided:
+                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, row_order=1)
+                    pool_i, pool_w = tree.query(pool_p, pool_seg, cap, r_normal, K)
             lv_points.append(points); lv_seg.append(seg); lv_conv.append(conv_i); lv_pool.append(pool_i)
+            lv_width.append((min(conv_w, K), min(pool_w, K)))                            # kpconv.py:255-258
             points, seg = pool_p, pool_seg
             r_normal *= 2
             layer += 1
@@ -83,7 +103,7 @@ class Preprocessor(nn.Module):
         # the one host round trip: level sizes
         seg_host = torch.stack(lv_seg).cpu().numpy()                                     # (levels, n_clouds + 1)
         data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
-                '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': []}
+                '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
         want64 = bool(cfg.get('kpconv_meta_int64', False))
         for l in range(len(lv_points)):
             n_l = int(seg_host[l, -1])
@@ -95,6 +115,10 @@ class Preprocessor(nn.Module):
             pool = lv_pool[l][:n_next] if lv_pool[l] is not None else torch.zeros((0, 1), dtype=torch.int32, device=device)
             data['_neighbors_i32'].append(conv)
             data['_pools_i32'].append(pool)
+            data['_pool_width'].append(lv_width[l][1])
+            if ref_order:        # the reference's table shapes: min(max in-ball count, K) columns (kpconv.py:255-258)
+                conv = conv[:, :lv_width[l][0]].contiguous() if lv_conv[l] is not None else conv
+                pool = pool[:, :lv_width[l][1]].contiguous() if lv_pool[l] is not None else pool
             data['neighbors'].append(conv.long() if want64 else conv)
             data['pools'].append(pool.long() if want64 else pool)
             data['upsamples'].append(torch.zeros((0, 1), dtype=torch.int64, device=device))
@@ -162,6 +186,7 @@ class _LevelView:
         self.s_pts = meta['points'][layer]
         self.q_pts = meta['points'][layer + 1] if strided else self.s_pts
         self.inds = meta['_pools_i32'][layer] if strided else meta['_neighbors_i32'][layer]
+        self.pool_width = meta['_pool_width'][layer] if strided else None
         self.seg_pre = meta['_seg_off'][layer]
         self.max_pre = max(meta['_lens_host'][layer])
         self.seg_post = meta['_seg_off'][layer + 1] if strided else self.seg_pre
@@ -217,7 +242,7 @@ class ResnetBottleneckBlock(nn.Module):
                             want_stats=(v.seg_post, v.max_post))                                              # :726
         # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
         y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
-        shortcut = ops.maxpool(features, v.inds) if strided else features                                     # :734-737
+        shortcut = ops.maxpool(features, v.inds, v.pool_width) if strided else features                                     # :734-737
         sc_st = None
         if isinstance(self.unary_shortcut, UnaryBlock):
             shortcut, sc_st = self.unary_shortcut.linear(shortcut, v.seg_post, v.max_post)

@@ -5,7 +5,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream
+from ._lib import bptr, check, dptr, iptr, ptr, raw, stream
 
 
 def _ws(nbytes, device):
@@ -13,17 +13,18 @@ def _ws(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ preprocessing
-def grid_subsample(xyz, seg_off, n_cap, dl):
+def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0):
     """xyz (n_cap,3) f32, seg_off (B+1,) i32 [device] -> (out_xyz (n_cap,3) [first out_seg_off[-1] rows live],
-    out_seg_off (B+1,) i32 [device]).  Row order: clouds stacked, voxels by first appearance."""
+    out_seg_off (B+1,) i32 [device]).  Row order: clouds stacked; voxels of a cloud by first appearance (row_order 0) or in
+    the reference's libstdc++ unordered_map iteration order (row_order 1, parity mode)."""
     L = _lib.lib()
     n_clouds = seg_off.numel() - 1
     out = torch.empty((max(n_cap, 1), 3), dtype=torch.float32, device=xyz.device)
     out_off = torch.empty(n_clouds + 1, dtype=torch.int32, device=xyz.device)
-    nb = L.regtr_grid_subsample_ws_bytes(n_cap, n_clouds)
+    nb = L.regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, int(row_order))
     ws = _ws(nb, xyz.device)
-    check(L.regtr_grid_subsample(ptr(xyz), ptr(seg_off), n_clouds, n_cap, float(dl), ptr(out), ptr(out_off),
-                                 ptr(ws), nb, stream()), 'regtr_grid_subsample')
+    check(L.regtr_grid_subsample_ordered(ptr(xyz), iptr(seg_off), n_clouds, n_cap, float(dl), int(row_order), ptr(out),
+                                         iptr(out_off), bptr(ws), nb, stream()), 'regtr_grid_subsample_ordered')
     return out, out_off
 
 
@@ -36,7 +37,7 @@ class CellGrid:
         self.s_seg_off, self.ns_cap, self.radius = s_seg_off, int(ns_cap), float(radius)
         self.nbytes = L.regtr_cellgrid_ws_bytes(self.ns_cap, self.n_clouds)
         self.ws = _ws(self.nbytes, s_xyz.device)
-        check(L.regtr_cellgrid_build(ptr(s_xyz), ptr(s_seg_off), self.n_clouds, self.ns_cap, self.radius, ptr(self.ws),
+        check(L.regtr_cellgrid_build(ptr(s_xyz), iptr(s_seg_off), self.n_clouds, self.ns_cap, self.radius, bptr(self.ws),
                                      self.nbytes, stream()), 'regtr_cellgrid_build')
 
     def query(self, q_xyz, q_seg_off, nq_cap, K, want_count=False):
@@ -46,10 +47,45 @@ class CellGrid:
         if want_count:
             cnt = torch.empty(max(nq_cap, 1), dtype=torch.int32, device=q_xyz.device)
             mx = torch.zeros(1, dtype=torch.int32, device=q_xyz.device)
-        check(L.regtr_radius_query(ptr(q_xyz), ptr(q_seg_off), int(nq_cap), ptr(self.s_seg_off), self.ns_cap,
-                                   self.n_clouds, self.radius, int(K), ptr(self.ws), self.nbytes, ptr(idx), ptr(cnt),
-                                   ptr(mx), stream()), 'regtr_radius_query')
+        check(L.regtr_radius_query(ptr(q_xyz), iptr(q_seg_off), int(nq_cap), iptr(self.s_seg_off), self.ns_cap,
+                                   self.n_clouds, self.radius, int(K), bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt),
+                                   iptr(mx), stream()), 'regtr_radius_query')
         return (idx, cnt, mx) if want_count else idx
+
+
+class KdTree:
+    """Parity mode (cfg.kpconv_ref_row_order): nanoflann-order neighbour tables (csrc/ref_order.hip).  Unlike CellGrid this
+    synchronises with the host (the list capacity must cover the largest in-ball count, known only after a first pass)."""
+
+    def __init__(self, s_xyz, s_seg_off, ns_cap):
+        L = _lib.lib()
+        self.n_clouds = s_seg_off.numel() - 1
+        self.s_xyz, self.s_seg_off, self.ns_cap = s_xyz, s_seg_off, int(ns_cap)
+        self.nbytes = L.regtr_kdtree_ws_bytes(self.ns_cap, self.n_clouds)
+        self.ws = _ws(self.nbytes, s_xyz.device)
+        check(L.regtr_kdtree_build(ptr(s_xyz), iptr(s_seg_off), self.n_clouds, self.ns_cap, bptr(self.ws), self.nbytes, stream()),
+              'regtr_kdtree_build')
+
+    def query(self, q_xyz, q_seg_off, nq_cap, radius, K, list_cap=128):
+        """-> (idx (nq_cap, K) i32 in the reference's row order, max in-ball count (host int))."""
+        L = _lib.lib()
+        dev = q_xyz.device
+        idx = torch.empty((max(nq_cap, 1), K), dtype=torch.int32, device=dev)
+        while True:
+            st = torch.zeros(2, dtype=torch.int32, device=dev)          # [max in-ball count, traversal-stack overflow]
+            sb = L.regtr_kdtree_query_scratch_bytes(int(list_cap))
+            scratch = _ws(sb, dev)
+            check(L.regtr_kdtree_radius_query(ptr(q_xyz), iptr(q_seg_off), int(nq_cap), ptr(self.s_xyz), iptr(self.s_seg_off),
+                                              self.ns_cap, self.n_clouds, float(radius), int(K), int(list_cap), bptr(self.ws),
+                                              self.nbytes, bptr(scratch), sb, iptr(idx), None, st.data_ptr(), st.data_ptr() + 4,
+                                              stream()), 'regtr_kdtree_radius_query')
+            max_count, overflow = (int(v) for v in st.cpu())
+            if overflow:
+                raise RuntimeError('regtr_kdtree_radius_query: traversal stack overflow (tree deeper than the parity mode supports)')
+            if max_count <= list_cap:
+                break
+            list_cap = max_count                 # a ball held more supports than the list: the sort needs them all, run again
+        return idx, max_count
 
 
 # ------------------------------------------------------------------------------------------------ dense
@@ -70,7 +106,7 @@ class SplitWeight:
         self.planes = None
         if L.regtr_gemm_x3_supported(1, self.N, self.K):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
-            check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, ptr(self.planes),
+            check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
                                              stream()), 'regtr_gemm_split_weights')
 
 
@@ -103,21 +139,21 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
             s_off = want_stats[0]
             n_clouds = s_off.numel() - 1
             partial = torch.empty((((M + R - 1) // R + n_clouds) * N, 2), dtype=torch.float64, device=a.device)
-        check(L.regtr_gemm_x3(a.data_ptr(), lda, ptr(sw.planes), out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
-                              residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
-                              ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, ptr(partial), ptr(s_off), n_clouds,
+        check(L.regtr_gemm_x3(raw(a), lda, bptr(sw.planes), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
+                              raw(residual), ldr, 1 if relu else 0,
+                              ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
                               stream()), 'regtr_gemm_x3')
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
-            check(L.regtr_instnorm_finalize_tiles(ptr(partial), ptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
+            check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
                   'regtr_instnorm_finalize_tiles')
             return out, stats
     else:
         nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
         ws = _ws(nb, a.device) if nb else None
-        check(L.regtr_gemm_f32(a.data_ptr(), lda, ptr(b_kn), N, out.data_ptr(), ldc, M, N, K, ptr(bias), ptr(row_div),
-                               residual.data_ptr() if residual is not None else None, ldr, 1 if relu else 0,
-                               ptr(a_stats), ptr(a_seg_off), n_seg, a_slope, ptr(ws), nb, stream()), 'regtr_gemm_f32')
+        check(L.regtr_gemm_f32(raw(a), lda, ptr(b_kn), N, raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
+                               raw(residual), ldr, 1 if relu else 0,
+                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, stream()), 'regtr_gemm_f32')
     if want_stats is not None:
         return out, instnorm_stats(out, want_stats[0], want_stats[1], eps)
     return out
@@ -173,9 +209,13 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     dev = x.device
     n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
     flag = None
-    if not L.regtr_kpconv_gather_computes_flag(Cin, H):      # otherwise the gather derives the flags from the rows it reads
+    # the matrix-core gather derives the positivity flags from the rows it reads; every other case (channel counts / row
+    # widths it does not take, unaligned views, >= 2^29 feature elements, no supports) needs them precomputed
+    fused_flag = (L.regtr_kpconv_gather_computes_flag(Cin, H) and x.data_ptr() % 16 == 0 and ns > 0 and ns * Cin < (1 << 29)
+                  and (x_stats is None or x_stats.data_ptr() % 16 == 0))
+    if not fused_flag:
         flag = torch.empty(ns, dtype=torch.float32, device=dev)
-        check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), ptr(s_seg_off) if x_stats is not None else None, n_seg,
+        check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), iptr(s_seg_off) if x_stats is not None else None, n_seg,
                                       slope, ptr(flag), stream()), 'regtr_rowsum_positive')
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
@@ -183,9 +223,9 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     if rec is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, ptr(nbr), H, ptr(x), Cin, ptr(flag),
+    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
-                                ptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
+                                iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
           'regtr_kpconv_gather')
     if rec is not None:
         e1.record()
@@ -200,11 +240,14 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
 gather_records = None
 
 
-def maxpool(x, nbr):
+def maxpool(x, nbr, width=None):
+    """max_pool (kpconv_blocks.py:127-143).  width: use only the first `width` columns of nbr -- the reference's CPU tables are
+    min(max in-ball count, K) wide (kpconv.py:255-258), so a full row holds no zero shadow row (parity mode)."""
     ns, C = x.shape
     nq, H = nbr.shape
     out = torch.empty((nq, C), dtype=torch.float32, device=x.device)
-    check(_lib.lib().regtr_maxpool_gather(ptr(x), ns, C, ptr(nbr), nq, H, ptr(out), stream()), 'regtr_maxpool_gather')
+    check(_lib.lib().regtr_maxpool_gather(ptr(x), ns, C, iptr(nbr), H, nq, H if width is None else int(width), ptr(out), stream()),
+          'regtr_maxpool_gather')
     return out
 
 
@@ -215,7 +258,7 @@ def instnorm_stats(x, seg_off, max_len, eps=1e-5):
     stats = torch.empty((n_clouds, C, 2), dtype=torch.float32, device=x.device)
     nb = L.regtr_instnorm_ws_bytes(n_clouds, max_len, C)
     ws = _ws(nb, x.device)
-    check(L.regtr_instnorm_stats(ptr(x), ptr(seg_off), n_clouds, int(max_len), C, eps, ptr(stats), ptr(ws), nb,
+    check(L.regtr_instnorm_stats(ptr(x), iptr(seg_off), n_clouds, int(max_len), C, eps, ptr(stats), bptr(ws), nb,
                                  stream()), 'regtr_instnorm_stats')
     return stats
 
@@ -225,7 +268,7 @@ def instnorm_apply(x, seg_off, max_len, stats, residual=None, res_stats=None, lr
     C = x.shape[1]
     if out is None:
         out = torch.empty_like(x)
-    check(_lib.lib().regtr_instnorm_apply(ptr(x), ptr(seg_off), n_clouds, int(max_len), C, ptr(stats), ptr(residual),
+    check(_lib.lib().regtr_instnorm_apply(ptr(x), iptr(seg_off), n_clouds, int(max_len), C, ptr(stats), ptr(residual),
                                           ptr(res_stats), 1 if lrelu else 0, slope, ptr(out), stream()),
           'regtr_instnorm_apply')
     return out
@@ -237,8 +280,8 @@ def mha(q, k, v, seg_off, kv_of, max_len, n_heads):
     N, E = q.shape
     hd = E // n_heads
     out = torch.empty((N, E), dtype=torch.float32, device=q.device)
-    check(_lib.lib().regtr_mha_fwd(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-                                   ptr(out), E, ptr(seg_off), ptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
+    check(_lib.lib().regtr_mha_fwd(raw(q), q.stride(0), raw(k), k.stride(0), raw(v), v.stride(0),
+                                   ptr(out), E, iptr(seg_off), iptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
                                    1.0 / math.sqrt(hd), stream()), 'regtr_mha_fwd')
     return out
 
@@ -247,7 +290,7 @@ def attn_xyz(q, k, xyz, seg_off, kv_of, max_len):
     """CorrespondenceDecoder.simple_attention: q, k (L, N, D) contiguous, xyz (N, 3) -> (L, N, 3)."""
     Lyr, N, D = q.shape
     out = torch.empty((Lyr, N, 3), dtype=torch.float32, device=q.device)
-    check(_lib.lib().regtr_attn_xyz(ptr(q), ptr(k), ptr(xyz), ptr(out), ptr(seg_off), ptr(kv_of), seg_off.numel() - 1, N, Lyr,
+    check(_lib.lib().regtr_attn_xyz(ptr(q), ptr(k), ptr(xyz), ptr(out), iptr(seg_off), iptr(kv_of), seg_off.numel() - 1, N, Lyr,
                                     int(max_len), D, 1.0 / math.sqrt(D), stream()), 'regtr_attn_xyz')
     return out
 
@@ -256,6 +299,6 @@ def weighted_procrustes(kp, corr, logit, seg_off, n_pairs):
     """kp (N,3), corr (L,N,3), logit (L,N), seg_off (2B+1,) i32 -> pose (L,B,3,4)."""
     Lyr, N = logit.shape
     pose = torch.empty((Lyr, n_pairs, 3, 4), dtype=torch.float32, device=kp.device)
-    check(_lib.lib().regtr_weighted_procrustes(ptr(kp), ptr(corr), ptr(logit), ptr(seg_off), n_pairs, N, Lyr, ptr(pose),
+    check(_lib.lib().regtr_weighted_procrustes(ptr(kp), ptr(corr), ptr(logit), iptr(seg_off), n_pairs, N, Lyr, ptr(pose),
                                                stream()), 'regtr_weighted_procrustes')
     return pose

@@ -15,7 +15,7 @@ import logging
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .config import as_config
 from .kpconv import KPFEncoder, PreprocessorGPU, _prepared
 from .transformer import TransformerCrossEncoder, TransformerCrossEncoderLayer
@@ -131,10 +131,21 @@ class RegTR(nn.Module):
 
     @torch.no_grad()
     def forward(self, batch):
-        B = len(batch['src_xyz'])
         dev = batch['src_xyz'][0].device
         if dev.type != 'cuda':
             raise RuntimeError('regtr_amd.RegTR runs on an MI355X (HIP) device only; there is no CPU path')
+        clouds = batch['src_xyz'] + batch['tgt_xyz']
+        if any(p.device != dev for p in clouds) or self.device != dev:
+            raise RuntimeError(f'RegTR.forward: the model ({self.device}) and every input cloud must live on one GPU ({dev})')
+        bad = [n for n, p in self.named_parameters() if p.dtype != torch.float32]
+        if bad:
+            raise RuntimeError(f'regtr_amd.RegTR computes in float32; non-float32 parameters: {bad[:3]} ...')
+        # kernels go to torch's current stream of the CURRENT device: make the tensors' device current for the whole forward
+        with _lib.on_device(dev):
+            return self._forward(batch, dev)
+
+    def _forward(self, batch, dev):
+        B = len(batch['src_xyz'])
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if _TIMEIT else None
         if ev: ev[0].record()
 

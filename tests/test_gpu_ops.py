@@ -259,6 +259,26 @@ def test_cpp_wrappers_dropin():
         radius_neighbors.batch_query(pts[:, :2], pts, lens, lens, radius=0.1)
 
 
+@pytest.mark.parametrize('case', ['modelnet', '3dmatch_crop'])
+def test_cpp_wrappers_reference_order(case):
+    """cpp_wrappers.reference_order(True): both drop-in ops return what the unmodified reference C++ returned (committed
+    fixtures made by oracle/make_golden.py) ELEMENT FOR ELEMENT -- subsampled rows in libstdc++ unordered_map iteration order,
+    neighbour rows in nanoflann visiting order + std::sort tie order, untruncated width."""
+    from regtr_amd import cpp_wrappers
+    g = gold(f'native_{case}')
+    pts, lens = g['pts'], g['lens']
+    prev = cpp_wrappers.reference_order(True)
+    try:
+        s_pts, s_len = cpp_wrappers.grid_subsampling.subsample_batch(pts, lens, sampleDl=float(g['dl']), max_p=0, verbose=0)
+        assert np.array_equal(s_len, g['sub_lens']) and np.array_equal(s_pts.view(np.uint32), g['sub_pts'].view(np.uint32))
+        nb = cpp_wrappers.radius_neighbors.batch_query(pts, pts, lens, lens, radius=float(g['radius']))
+        assert np.array_equal(nb, g['neighbors'])
+        pool = cpp_wrappers.radius_neighbors.batch_query(s_pts, pts, s_len, lens, radius=float(g['radius']))
+        assert np.array_equal(pool, g['pools'])
+    finally:
+        cpp_wrappers.reference_order(prev)
+
+
 # ------------------------------------------------------------------------------------------------ encoder kernels
 @pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40),
                                         (16, 64, 40), (48, 32, 40), (20, 12, 33)])      # last three: general LDS-tile gather + flag pass
