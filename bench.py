@@ -1,7 +1,10 @@
 """Throughput benchmark of the RegTR correspondence-inference hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1: either launched by the driver as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py
+    --gpus N ...`, or plainly as `python bench.py --gpus N` -- the script then re-executes itself under
+    torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous).  A world size that differs from --gpus is an error,
+    and `n_gpus` in the JSON line is the number of ranks whose poses arrived through the RCCL all_gather.
 
 A "step" is one forward of the hot path (preprocess -> KPConv encoder -> 6 cross-attention layers -> head ->
 weighted Procrustes) over one batch of `--pairs` synthetic 3DMatch-sized pairs (BASELINE.json configs[2]: ~20k points
@@ -13,6 +16,8 @@ Rank 0 prints ONE JSON line (metric pairs/s, whole-job aggregate) with `roofline
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -160,6 +165,30 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0):
                       f'median s/pair {med:.2f} = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'}
 
 
+def run_stub(args, rank, world, dist):
+    """tests/test_bench_entry.py: the launch / sharding / gather / reporting logic of this script on CPU (gloo) with a
+    stand-in for the forward -- no kernels, no claims; prints the same JSON shape with metric 'stub'."""
+    from regtr_amd.distributed import gather_poses
+    pair_ids = torch.arange(args.pairs, dtype=torch.int32) + rank * args.pairs
+    eye = torch.eye(3, 4).reshape(1, 12).repeat(args.pairs, 1)
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        poses = eye + pair_ids[:, None].float()
+    all_poses, all_ids = gather_poses(poses, pair_ids) if dist else (poses, pair_ids)
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ranks_seen = int(torch.unique(torch.div(all_ids, args.pairs, rounding_mode='floor')).numel())
+    assert all_poses.shape[0] == args.pairs * world and ranks_seen == world
+    assert torch.equal(all_poses[:, 0], 1 + all_ids.float())
+    if rank == 0:
+        print(json.dumps({'metric': 'stub', 'value': world * args.steps * args.pairs / max(elapsed, 1e-9), 'unit': 'pairs/s',
+                          'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup}))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -170,19 +199,39 @@ def main():
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs')
+    stub = args.stub_backend is not None      # tests only: the multi-process entry logic on CPU (gloo), no kernels
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if stub:
+            dist.init_process_group(args.stub_backend)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if stub:
+        return run_stub(args, rank, world, dist)
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        sys.exit(f'bench.py: rank {rank} needs GPU {local_rank}; {torch.cuda.device_count()} visible (there is no CPU path)')
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -217,12 +266,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert all_poses.shape[0] == args.pairs * world and torch.isfinite(all_poses).all()
+    ranks_seen = int(torch.unique(torch.div(all_ids, args.pairs, rounding_mode='floor')).numel())   # who entered the all_gather
+    assert ranks_seen == world, (ranks_seen, world)
 
     if rank == 0:
         total_pairs = world * args.steps * args.pairs
         res = {
             'metric': 'point-cloud pairs/sec (3DMatch ~20k pts)', 'value': total_pairs / elapsed, 'unit': 'pairs/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'BASELINE configs[2]: 3DMatch-size pairs, full KPConv encoder + 6-layer cross-attn + SVD',
                        'pairs_per_step_per_gpu': args.pairs,

@@ -1,0 +1,31 @@
+"""CPU: bench.py's multi-GPU entry logic -- self-launch under torch.distributed.run, world-size check, pose gather, the
+reported n_gpus -- on gloo with a stand-in forward (`--stub-backend gloo`; the real forward needs MI355X kernels)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=env,
+                          timeout=300)
+
+
+def test_plain_invocation_self_launches_two_ranks():
+    r = _run(['--gpus', '2', '--steps', '3', '--warmup', '1', '--pairs', '5', '--stub-backend', 'gloo'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(line) == 1, r.stdout                       # rank 0 only
+    d = json.loads(line[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['value'] > 0
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(['--gpus', '2', '--stub-backend', 'gloo'], {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0 and 'refusing' in (r.stderr + r.stdout)
+    r = _run(['--gpus', '1', '--stub-backend', 'gloo', '--steps', '1', '--pairs', '2'])
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])['n_gpus'] == 1
