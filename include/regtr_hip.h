@@ -77,6 +77,20 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
                        int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
                        int* out_count, int* out_max_count, void* stream);
 
+/* ---- ground-truth overlap (training / validation side) ------------------------------------------- */
+
+/* utils/pointcloud.py:8-65 compute_overlap: index of the NEAREST support of the query's cloud with d2 < radius^2, distances
+ * in float64 like open3d's KDTreeFlann (float32 coordinates widened), -1 when the ball is empty.  Query cloud c searches
+ * support cloud c (stack src clouds as supports and tgt clouds as queries, then the other way round).  grid_ws: a cell grid
+ * built by regtr_cellgrid_build over the supports with grid_radius * (1 + 1e-6) >= radius.  out_idx [nq_cap]. */
+int regtr_nearest_in_radius(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
+                            int n_clouds, double radius, float grid_radius, const void* grid_ws, size_t ws_bytes, int* out_idx,
+                            void* stream);
+
+/* models/backbone_kpconv/kpconv.py:553-562 compute_overlaps, one pyramid level: out[q] = clamp(mean of ov over the valid
+ * (< ns) entries of the first H columns of row q of nbr, 0, 1); a row without a valid entry gives NaN as in the reference. */
+int regtr_overlap_avgpool(const float* ov, int ns, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream);
+
 /* Parity mode (cfg.kpconv_ref_row_order): the same neighbour sets in the REFERENCE's row order -- nanoflann's KD-tree
  * visiting order passed through std::sort on the distance alone (neighbors.cpp:246-267, nanoflann.hpp:857-1003,1348-1412,
  * 1285-1287) -- so that rows truncated to K keep the very supports the reference keeps when distances tie.  One thread
@@ -174,9 +188,12 @@ int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale
 
 /* ---- attention + pose -------------------------------------------------------------------------------------- */
 
+/* softmax(q k^T * scale) v per head on packed clouds: cloud c's rows attend the rows of cloud kv_of[c]; head_dim = 32.
+ * precision: 0 = float32-grade on the bf16 matrix cores (every operand split exactly into three bf16, six MFMAs per product;
+ * default), 1 = plain bf16 operands with float32 softmax / accumulation (cfg.compute_dtype 'bf16'), 2 = exact-f32 MFMA. */
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
-                  void* stream);
+                  int precision, void* stream);
 
 /* CorrespondenceDecoder.simple_attention (regtr.py:316-351, `direct_regress_coor: False`): single-head attention whose values
  * are coordinates.  q, k [n_layers, n_total, head_dim] contiguous (projections of the conditioned features), xyz [n_total,3],

@@ -76,6 +76,22 @@ def run_case(name, cfg_name, src, tgt, with_feats=False, overrides=None):
     print('  pose[-1]:\n', g['pose'][-1, 0])
 
 
+def overlaps_case(name, cfg_name, src, tgt):
+    """The reference's own compute_overlaps (kpconv.py:540-566) on the reference Preprocessor's pyramid with seeded random
+    level-0 masks -> tests/golden/overlaps_<name>.npz."""
+    ref = ref_loader.load()
+    cfg = ref_loader.load_cfg(cfg_name)
+    pre = ref.kpconv.Preprocessor(cfg)
+    meta = pre([torch.from_numpy(src), torch.from_numpy(tgt)])
+    rng = np.random.default_rng(5)
+    so, to = rng.random(len(src)) < 0.6, rng.random(len(tgt)) < 0.3
+    batch = {'src_overlap': [torch.from_numpy(so)], 'tgt_overlap': [torch.from_numpy(to)], 'kpconv_meta': meta}
+    pyr = ref.kpconv.compute_overlaps(batch)
+    np.savez_compressed(os.path.join(GOLD, f'overlaps_{name}.npz'), src=src, tgt=tgt, src_overlap=so, tgt_overlap=to,
+                        **{k: v.numpy() for k, v in pyr.items()})
+    print('overlaps', name, {k: (tuple(v.shape), float(np.nanmean(v.numpy()))) for k, v in pyr.items()})
+
+
 def native_case(name, pts, lens, dl, radius):
     rp, rl = native.ref_subsample_batch(pts, lens, dl)
     nb = native.ref_batch_query(pts, pts, lens, lens, radius)
@@ -101,6 +117,9 @@ def main():
     native_case('modelnet', np.concatenate([m0, m1]), np.array([len(m0), len(m1)], np.int32), 0.06, 0.0825)
     n0, n5 = crop(k0, 0.5), crop(k5, 0.5)
     native_case('3dmatch_crop', np.concatenate([n0, n5]), np.array([len(n0), len(n5)], np.int32), 0.05, 0.0625)
+    overlaps_case('3dmatch_crop', '3dmatch', c0, c5)
+    if os.environ.get('GOLDEN_ONLY') == 'overlaps':
+        return
     run_case('modelnet_demo', 'modelnet', m0, m1)
     run_case('3dmatch_crop', '3dmatch', c0, c5, with_feats=True)
     run_case('3dmatch_kitchen', '3dmatch', k0, k5)

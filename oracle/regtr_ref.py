@@ -314,6 +314,47 @@ def compute_rigid_transform(a, b, weights):
 # ------------------------------------------------------------------------------------------------
 # RegTR.forward  (models/regtr.py:104-235)
 # ------------------------------------------------------------------------------------------------
+# ground-truth overlap (training / validation side)
+# ------------------------------------------------------------------------------------------------
+def compute_overlaps(batch):
+    """models/backbone_kpconv/kpconv.py:540-566."""
+    overlaps = list(batch['src_overlap']) + list(batch['tgt_overlap'])
+    meta = batch['kpconv_meta']
+    pyr = {'pyr_0': torch.cat(overlaps, 0).type(torch.float)}                       # :553
+    invalid = [s.sum() for s in meta['stack_lengths']]                                # :554
+    for p in range(1, len(meta['points'])):
+        pools = meta['pools'][p - 1].clone().long()
+        valid = pools < invalid[p - 1]                                               # :557
+        pools[~valid] = 0
+        g = pyr[f'pyr_{p - 1}'][pools] * valid                                       # :561
+        g = torch.sum(g, dim=1) / torch.sum(valid, dim=1)                            # :562
+        pyr[f'pyr_{p}'] = torch.clamp(g, min=0, max=1)                               # :563
+    return pyr
+
+
+def compute_overlap(src, tgt, search_voxel_size):
+    """utils/pointcloud.py:8-65 with open3d's KDTreeFlann.search_radius_vector_3d (open3d is not installed here: PARITY
+    UNPINNED for this one function) restated from its documented behaviour: coordinates widened to float64, hits are the
+    points with d2 < radius^2 sorted by distance, `knn_indices[0]` the nearest.  Brute force, small clouds only."""
+    src = np.asarray(src, np.float64); tgt = np.asarray(tgt, np.float64)
+    r2 = float(search_voxel_size) ** 2
+
+    def nearest(q, s):
+        out = np.full(len(q), -1, np.int64)
+        for i0 in range(0, len(q), 512):
+            d = q[i0:i0 + 512, None, :] - s[None]
+            d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+            j = np.argmin(d2, 1)
+            hit = d2[np.arange(len(j)), j] < r2
+            out[i0:i0 + 512][hit] = j[hit]
+        return out
+    tgt_corr = nearest(tgt, src)                                                     # :44-49
+    src_corr = nearest(src, tgt)                                                     # :50-55
+    mutual = np.logical_and(tgt_corr[src_corr] == np.arange(len(src_corr)), src_corr > 0)   # :58-59
+    return src_corr >= 0, tgt_corr >= 0, np.stack([np.nonzero(mutual)[0], src_corr[mutual]])
+
+
+# ------------------------------------------------------------------------------------------------
 def regtr_forward(sd, cfg, src_list, tgt_list, meta=None, use_ref_cpp=False, timings=None):
     """Returns the reference's outputs dict (regtr.py:218-235) + 'kpconv_meta'."""
     import time

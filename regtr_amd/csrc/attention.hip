@@ -139,6 +139,212 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The same attention on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the f32-MFMA rate on gfx950), float32
+// softmax and accumulation.  NP = number of bf16 planes every operand is split into:
+//   NP = 3  float32-grade: q, k, v and the probabilities are EXACT sums of three bf16 (x = x0 + x1 + x2) and each product is
+//           six MFMAs, smallest terms first (see gemm_x3.hip) -- the default; 2.7x fewer matrix-pipe cycles than the f32 MFMA;
+//   NP = 1  plain bf16 operands (cfg.compute_dtype = 'bf16', BASELINE configs[1]): one MFMA per product.
+// Workgroup = 4 waves = four 32-query tiles of one (cloud, head) sharing every K / V tile: the 256 threads load one float4 of K
+// and two float2 of V each, split them once, and stage them into double-buffered LDS (K row-major, V TRANSPOSED -- the A
+// operand of O^T += V^T P^T is 8 consecutive contraction slots of one head channel); the next tile's global loads are issued
+// before the MFMAs of the current one; one barrier per tile.  LDS rows are 64 B (32 bf16) with the four 16-byte chunks of
+// row r at chunk ^ ((r >> 2) & 3): conflict-free ds_read_b128 fragments.  As in k_mha_fwd, S^T = K Q^T leaves every lane with
+// ONE query's scores, and P^T goes back in as the B operand without leaving registers: contraction slot j of k-step ks of
+// half-wave hi is the key accumulator register 8 ks + j of that half-wave belongs to, so V^T is stored with its key columns
+// permuted accordingly (bits 2 and 3 of the key index swapped).  Scores carry log2(e): softmax uses the hardware exp2.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+constexpr int BW = 4;                 // waves (32-query tiles) per workgroup
+constexpr int BROW = 64;              // bytes per LDS row
+
+__device__ __forceinline__ unsigned bf_pack(float a, float b)
+{
+    bf16x2v v;
+    v.x = (__bf16)a; v.y = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+// (a, b) -> NP packed bf16 pairs; for NP = 3: a = a0 + a1 + a2 exactly (likewise b)
+template <int NP>
+__device__ __forceinline__ void bf_split2(float a, float b, unsigned (&p)[NP])
+{
+    p[0] = bf_pack(a, b);
+    if (NP > 1) {
+        const float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
+        p[1] = bf_pack(ra, rb);
+        if (NP > 2) p[2] = bf_pack(ra - __uint_as_float(p[1] << 16), rb - __uint_as_float(p[1] & 0xffff0000u));
+    }
+}
+// 8 floats -> NP fragments of 8 bf16
+template <int NP>
+__device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 (&f)[NP])
+{
+    unsigned w[4][NP];
+#pragma unroll
+    for (int i = 0; i < 4; i++) bf_split2<NP>(x[2 * i], x[2 * i + 1], w[i]);
+#pragma unroll
+    for (int p = 0; p < NP; p++) f[p] = __builtin_bit_cast(bf16x8, make_uint4(w[0][p], w[1][p], w[2][p], w[3][p]));
+}
+// A x B with both operands split: the NP (NP + 1) / 2 terms whose exponent sum stays below NP, smallest first
+template <int NP>
+__device__ __forceinline__ floatx16 bf_mma(const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], floatx16 c)
+{
+    if (NP == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+    }
+    if (NP >= 2) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+}
+
+template <int NP>
+__global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
+{
+    __shared__ __align__(16) unsigned char Ks[2][NP][TK * BROW];      // [buffer][plane][key][32 channels]
+    __shared__ __align__(16) unsigned char Vt[2][NP][HD * BROW];      // [buffer][plane][channel][32 key slots]
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cloud = blockIdx.z, head = blockIdx.y;
+    const int q_begin = g.seg_off[cloud], q_end = g.seg_off[cloud + 1];
+    if (q_begin + (int)blockIdx.x * BW * TQ >= q_end) return;          // the whole workgroup (before any barrier)
+    const int q0 = q_begin + (blockIdx.x * BW + wave) * TQ;
+    const bool wave_live = q0 < q_end;                                 // wave-uniform; dead waves still stage K / V
+    const int kc = g.kv_of[cloud];
+    const int k_begin = g.seg_off[kc], nk = g.seg_off[kc + 1] - k_begin;
+    const int hoff = head * HD;
+
+    // B operand of S^T = K Q^T: lane (query l31, half hi) holds Q[q][16 ks + 8 hi + j] * scale * log2(e), j < 8
+    bf16x8 qf[2][NP];
+    {
+        const int qrow = q0 + l31;
+        const bool live = wave_live && qrow < q_end;
+        const float sc2 = g.scale * 1.44269504088896340736f;
+        const float* qp = g.q + (size_t)(live ? qrow : q_begin) * g.ldq + hoff + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) x[j] = live ? qp[16 * ks + j] * sc2 : 0.f;
+            bf_split8<NP>(x, qf[ks]);
+        }
+    }
+
+    // staging roles: K -- thread (key = t / 8, channels 4 (t % 8) ..+3); V -- thread (key pair u = t / 16, channels 2 (t % 16), +1)
+    const int skey = t >> 3, sd4 = (t & 7) * 4;
+    const int su = t >> 4, sd2 = (t & 15) * 2;
+    const unsigned k_dst = (unsigned)skey * BROW + (((unsigned)(sd4 >> 3) ^ (((unsigned)skey >> 2) & 3u)) * 16u) + ((unsigned)t & 1u) * 8u;
+    const unsigned vpos = ((2u * su) & 0x13u) | (((2u * su) & 4u) << 1) | (((2u * su) & 8u) >> 1);     // slot of key 2 u (even)
+    unsigned v_dst[2];
+#pragma unroll
+    for (int dd = 0; dd < 2; dd++) {
+        const unsigned row = (unsigned)(sd2 + dd);
+        v_dst[dd] = row * BROW + (((vpos >> 3) ^ ((row >> 2) & 3u)) * 16u) + (vpos & 7u) * 2u;
+    }
+    float4 kreg;
+    float2 vreg0, vreg1;
+    auto fetch = [&](int kt) {
+        const int kr = kt + skey, v0 = kt + 2 * su;
+        kreg = make_float4(0.f, 0.f, 0.f, 0.f);
+        vreg0 = make_float2(0.f, 0.f); vreg1 = vreg0;
+        if (kr < nk) kreg = *(const float4*)(g.k + (size_t)(k_begin + kr) * g.ldk + hoff + sd4);
+        if (v0 < nk) vreg0 = *(const float2*)(g.v + (size_t)(k_begin + v0) * g.ldv + hoff + sd2);
+        if (v0 + 1 < nk) vreg1 = *(const float2*)(g.v + (size_t)(k_begin + v0 + 1) * g.ldv + hoff + sd2);
+    };
+    auto stage = [&](int buf) {
+        unsigned a[NP], b[NP];
+        bf_split2<NP>(kreg.x, kreg.y, a);
+        bf_split2<NP>(kreg.z, kreg.w, b);
+#pragma unroll
+        for (int p = 0; p < NP; p++) *(uint2*)(&Ks[buf][p][k_dst]) = make_uint2(a[p], b[p]);
+        bf_split2<NP>(vreg0.x, vreg1.x, a);           // (key 2u, key 2u + 1) of channel sd2
+        bf_split2<NP>(vreg0.y, vreg1.y, b);           // ... of channel sd2 + 1
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            *(unsigned*)(&Vt[buf][p][v_dst[0]]) = a[p];
+            *(unsigned*)(&Vt[buf][p][v_dst[1]]) = b[p];
+        }
+    };
+
+    floatx16 o;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    unsigned f_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) f_off[ks] = (unsigned)l31 * BROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = 0; kt < nk; kt += TK, buf ^= 1) {
+        const bool more = kt + TK < nk;                // workgroup-uniform
+        if (more) fetch(kt + TK);
+        if (wave_live) {
+            floatx16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                bf16x8 kf[NP];
+#pragma unroll
+                for (int p = 0; p < NP; p++) kf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Ks[buf][p][f_off[ks]]));
+                sc = bf_mma<NP>(kf, qf[ks], sc);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (kt + acc_row(r, hi) >= nk) sc[r] = -INFINITY;
+                mx = fmaxf(mx, sc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, RG_WAVE));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            float psum = 0.f;
+            float pr[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
+                psum += pr[r];
+            }
+            psum += __shfl_xor(psum, 32, RG_WAVE);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r] *= alpha;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) x[j] = pr[8 * ks + j];
+                bf16x8 pf[NP], vf[NP];
+                bf_split8<NP>(x, pf);
+#pragma unroll
+                for (int p = 0; p < NP; p++) vf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Vt[buf][p][f_off[ks]]));
+                o = bf_mma<NP>(vf, pf, o);
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int qrow = q0 + l31;
+    if (wave_live && qrow < q_end) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // empty key set -> zeros
+        float* dst = g.out + (size_t)qrow * g.ldo + hoff;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+            const int d = 8 * r4 + 4 * hi;
+            *(float4*)(dst + d) = make_float4(o[4 * r4] * inv, o[4 * r4 + 1] * inv, o[4 * r4 + 2] * inv, o[4 * r4 + 3] * inv);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Single-head dot-product attention whose VALUES are coordinates: CorrespondenceDecoder.simple_attention
 // (/root/reference/src/models/regtr.py:316-351, the `direct_regress_coor: False` head).  out[l, q, :] =
 // softmax_s( Q[l, q, :] . K[l, s, :] * scale ) @ xyz[s, :]  over the keys s of the partner cloud kv_of[cloud(q)], for every
@@ -247,16 +453,25 @@ extern "C" {
 // q, k, v: [N_total, *] row-major views (leading dims ldq/ldk/ldv) holding n_heads * 32 columns each;
 // out [N_total, ldo].  seg_off [n_clouds + 1] and kv_of [n_clouds] live on the device.
 // max_len = longest query segment (host-known bound used for the launch grid).
+// precision: 0 = float32-grade on the bf16 matrix cores (three-way split operands, default), 1 = plain bf16 operands
+// (float32 softmax / accumulation), 2 = the exact-f32 MFMA kernel (one wave per 32-query tile; the A/B reference).
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
-                  void* stream)
+                  int precision, void* stream)
 {
     if (!q || !k || !v || !out || !seg_off || !kv_of || n_clouds < 1 || n_heads < 1 || max_len < 0) return RG_ERR_ARG;
-    if (head_dim != HD) return RG_ERR_ARG;
+    if (head_dim != HD || precision < 0 || precision > 2) return RG_ERR_ARG;
     if ((ldk | ldv | ldo) % 4 || (((uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
     MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
-    k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, (hipStream_t)stream>>>(g);
+    hipStream_t st = (hipStream_t)stream;
+    if (precision == 2) k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, st>>>(g);
+    else {
+        if ((ldv % 2) || ((uintptr_t)v % 8)) return RG_ERR_ARG;
+        const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);
+        if (precision == 0) k_mha_fwd_bf16<3><<<grid, BW * RG_WAVE, 0, st>>>(g);
+        else k_mha_fwd_bf16<1><<<grid, BW * RG_WAVE, 0, st>>>(g);
+    }
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

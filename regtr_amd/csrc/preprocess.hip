@@ -594,6 +594,55 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     }
 }
 
+// Nearest support inside the ball, in float64 -- the ground-truth overlap test of the reference's data pipeline
+// (utils/pointcloud.py:8-65: open3d KDTreeFlann.search_radius_vector_3d on double coordinates, d2 < r^2, first = nearest).
+// One thread per query over the 27 cells of the support grid; ties on d2 go to the lower index.  Not on the inference
+// path, so no wave-level machinery.
+__global__ void __launch_bounds__(256) k_nearest_in_radius(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_off,
+                                                           const int* __restrict__ s_seg_off, int n_clouds, GridView g, double r2,
+                                                           int* __restrict__ out_idx)
+{
+    const int nq = q_seg_off[n_clouds], ns = s_seg_off[n_clouds];
+    const unsigned mask = rg_live_table(ns) - 1u;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        const int cid = rg_find_segment(q_seg_off, n_clouds, q);
+        const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
+        int64_t cx, cy, cz;
+        cell_of(qx, qy, qz, g.inv_cs, cx, cy, cz);
+        double best = r2;
+        int best_i = -1;
+        for (int c = 0; c < 27; c++) {
+            int cnt, start;
+            slot_find(g.slots, mask, cell_key(cx + c % 3 - 1, cy + (c / 3) % 3 - 1, cz + c / 9 - 1), cid, cnt, start);
+            for (int t = 0; t < cnt; t++) {
+                const float4 sp = g.sorted[start + t];
+                const double dx = (double)qx - (double)sp.x, dy = (double)qy - (double)sp.y, dz = (double)qz - (double)sp.z;
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                const int i = __float_as_int(sp.w);
+                if (d2 < best || (d2 == best && best_i >= 0 && i < best_i)) { best = d2; best_i = i; }
+            }
+        }
+        out_idx[q] = best_i;
+    }
+}
+
+// overlap_pyr[p][q] = clamp(mean over the valid entries of pools row q of overlap_pyr[p-1], 0, 1)   (kpconv.py:553-562;
+// a row without a valid entry is 0/0 = NaN there and here)
+__global__ void __launch_bounds__(256) k_overlap_avgpool(const float* __restrict__ ov, int ns, const int* __restrict__ nbr, int ld,
+                                                         int nq, int H, float* __restrict__ out)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float sum = 0.f, cnt = 0.f;
+    for (int h = 0; h < H; h++) {
+        const int i = nbr[(size_t)q * ld + h];
+        if (i < ns) { sum += ov[i]; cnt += 1.f; }
+    }
+    const float v = sum / cnt;
+    out[q] = fminf(fmaxf(v, 0.f), 1.f);       // torch.clamp propagates NaN; fminf/fmaxf would not:
+    if (v != v) out[q] = v;
+}
+
 struct GridBuffers {
     uint64_t* pkey; int* pcid; int* slot_of; int* rep; int* cnt; int* fill;
     uint64_t* tkey; int* tcid; uint64_t* scan_in; uint64_t* cell_start; uint64_t* bsum; float4* sorted; CellSlot* slots;
@@ -761,6 +810,34 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_cdiv(nq_cap, QUERY_WAVES) : 256 * 64;   // grid-stride inside
     k_radius_query<<<grid, QUERY_WAVES * RG_WAVE, lds, st>>>(
         q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, out_idx, out_count, out_max_count);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// Index (into the stacked supports) of the nearest support of the query's cloud with d2 < radius^2 in float64, -1 if none
+// (utils/pointcloud.py:44-55).  grid_ws: a cell grid built over the supports with cell size >= radius.
+int regtr_nearest_in_radius(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
+                            int n_clouds, double radius, float grid_radius, const void* grid_ws, size_t ws_bytes, int* out_idx,
+                            void* stream)
+{
+    if (!q_xyz || !q_seg_off || !s_seg_off || !out_idx || !grid_ws || n_clouds < 1 || !(radius > 0.0) ||
+        !((double)grid_radius * (1.0 + 1e-6) >= radius))
+        return RG_ERR_ARG;
+    if (ws_bytes < regtr_cellgrid_ws_bytes(ns_cap, n_clouds)) return RG_ERR_WORKSPACE;
+    if (nq_cap <= 0) return RG_OK;
+    GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap > 0 ? ns_cap : 1);
+    GridView g{b.slots, b.sorted, 1.0 / ((double)grid_radius * (1.0 + 1e-6))};
+    const int blocks = rg_cdiv(nq_cap, 256) < 4096 ? rg_cdiv(nq_cap, 256) : 4096;
+    k_nearest_in_radius<<<blocks, 256, 0, (hipStream_t)stream>>>(q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius * radius, out_idx);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+int regtr_overlap_avgpool(const float* ov, int ns, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream)
+{
+    if (!ov || !nbr || !out || ns < 0 || nq < 0 || H < 1 || ld_nbr < H) return RG_ERR_ARG;
+    if (nq == 0) return RG_OK;
+    k_overlap_avgpool<<<rg_cdiv(nq, 256), 256, 0, (hipStream_t)stream>>>(ov, ns, nbr, ld_nbr, nq, H, out);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

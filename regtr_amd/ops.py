@@ -275,14 +275,15 @@ def instnorm_apply(x, seg_off, max_len, stats, residual=None, res_stats=None, lr
 
 
 # ------------------------------------------------------------------------------------------------ attention + pose
-def mha(q, k, v, seg_off, kv_of, max_len, n_heads):
-    """q, k, v: (N, E) column views of a packed projection; returns (N, E) concatenated heads."""
+def mha(q, k, v, seg_off, kv_of, max_len, n_heads, precision=0):
+    """q, k, v: (N, E) column views of a packed projection; returns (N, E) concatenated heads.
+    precision: 0 float32-grade (bf16x3 split MFMA), 1 plain bf16 operands, 2 exact-f32 MFMA (see regtr_hip.h)."""
     N, E = q.shape
     hd = E // n_heads
     out = torch.empty((N, E), dtype=torch.float32, device=q.device)
     check(_lib.lib().regtr_mha_fwd(raw(q), q.stride(0), raw(k), k.stride(0), raw(v), v.stride(0),
                                    ptr(out), E, iptr(seg_off), iptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
-                                   1.0 / math.sqrt(hd), stream()), 'regtr_mha_fwd')
+                                   1.0 / math.sqrt(hd), int(precision), stream()), 'regtr_mha_fwd')
     return out
 
 

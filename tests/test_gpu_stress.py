@@ -1,12 +1,16 @@
-"""GPU (-m gpu): BASELINE.json configs[4] -- a synthetic 100k + 100k-point pair -- checked through size-independent
-properties (the brute-force oracle is quadratic and would take minutes at this size): neighbour rows against an exact
-float32 brute-force on sampled queries, sortedness / radius / padding invariants on every row, subsampling bit-exact
-against the (linear-time) C++ oracle, and forward invariants (batch independence, finite orthonormal poses)."""
+"""GPU (-m gpu): BASELINE.json configs[4] -- a synthetic 100k + 100k-point pair.
+  * every neighbour / pool table of the pyramid, full size, against the unmodified reference C++ (oracle/_ref: KD-tree, fast)
+    through the canonical (d2, index) order; the same tables in PARITY mode equal the reference's element for element;
+  * subsampling bit-exact against the (linear-time) C++ oracle at every level;
+  * the forward against the CPU oracle restatement on the full stress pair (tables for the oracle come from oracle/_ref, the
+    quadratic brute-force restatement being too slow at this size);
+  * size-independent properties as a second line: invariants on every row, exact brute force on sampled queries, batch
+    independence, orthonormal poses."""
 import numpy as np
 import pytest
 import torch
 
-from tests.util import load_cfg, seeded_sd, seg_of, to_dev
+from tests.util import canon_table, load_cfg, seeded_sd, seg_of, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -81,3 +85,80 @@ def test_stress_100k_forward_invariants():
     assert (one['src_kp_warped'][0] - two['src_kp_warped'][0]).abs().max() < 1e-4          # pairs are independent
     assert (one['pose'][:, 0] - two['pose'][:, 0]).abs().max() < 1e-4
     assert 1000 < len(one['src_kp'][0]) < 8000                                              # ~2k tokens per cloud at this size
+
+
+def _ref_canonical_meta(pts_list, cfg):
+    """kpconv_meta in the product's canonical orders at stress size: first-appearance subsampling from the (linear-time) C++
+    oracle, neighbour sets from the unmodified reference C++ (KD-tree) re-ordered to (d2, index) and cut at K."""
+    from oracle import native
+    pts = np.concatenate(pts_list).astype(np.float32); lens = np.array([len(p) for p in pts_list], np.int32)
+    limits = cfg['neighborhood_limits']
+    r = cfg['first_subsampling_dl'] * cfg['conv_radius']
+    meta = {k: [] for k in ('points', 'neighbors', 'pools', 'upsamples', 'stack_lengths')}
+    n_levels = 1 + sum(('strided' in b or 'pool' in b) for b in cfg['architecture'])
+    for l in range(n_levels):
+        K = limits[l]
+        conv = canon_table(native.ref_batch_query(pts, pts, lens, lens, r), pts, pts, len(pts), K)
+        if l + 1 < n_levels:
+            sub, sl = native.grid_subsample(pts, lens, 2 * r / cfg['conv_radius'])
+            pool = canon_table(native.ref_batch_query(sub, pts, sl, lens, r), sub, pts, len(pts), K)
+        else:
+            sub, sl, pool = np.zeros((0, 3), np.float32), np.zeros(0, np.int32), np.zeros((0, 1), np.int32)
+        meta['points'].append(torch.from_numpy(pts)); meta['neighbors'].append(torch.from_numpy(conv.astype(np.int64)))
+        meta['pools'].append(torch.from_numpy(pool.astype(np.int64))); meta['upsamples'].append(torch.zeros((0, 1), dtype=torch.int64))
+        meta['stack_lengths'].append(torch.from_numpy(lens.astype(np.int64)))
+        pts, lens, r = sub, sl, r * 2
+    return meta
+
+
+def test_stress_100k_full_tables_and_forward_vs_oracle():
+    """Full-size check of configs[4]: every table of the pyramid == the reference C++'s neighbour sets in canonical order,
+    and the whole forward == the CPU oracle restatement (1e-4) on the 100k + 100k pair."""
+    from oracle import native, regtr_ref
+    from regtr_amd import RegTR
+    if not native.have_ref():
+        pytest.skip('oracle/_ref not present')
+    src, tgt = _pair()
+    cfg = load_cfg('3dmatch')
+    sd = seeded_sd(cfg)
+    model = RegTR(cfg)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    batch = {'src_xyz': [torch.from_numpy(src).cuda()], 'tgt_xyz': [torch.from_numpy(tgt).cuda()]}
+    out = model(batch)
+    torch.cuda.synchronize()
+    meta = batch['kpconv_meta']
+    rmeta = _ref_canonical_meta([src, tgt], cfg)
+    for l in range(len(rmeta['points'])):
+        assert torch.equal(meta['points'][l].cpu(), rmeta['points'][l]), l
+        assert torch.equal(meta['neighbors'][l].cpu().long(), rmeta['neighbors'][l]), l
+        if rmeta['pools'][l].numel():
+            assert torch.equal(meta['pools'][l].cpu().long(), rmeta['pools'][l]), l
+    with torch.no_grad():
+        ref = regtr_ref.regtr_forward(sd, cfg, [src], [tgt], meta=rmeta)
+    worst = {k: (out[k][0].cpu() - ref[k][0]).abs().max().item() for k in ('src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap')}
+    worst['pose'] = (out['pose'].cpu() - ref['pose']).abs().max().item()
+    print('stress 100k+100k forward, max abs diff vs oracle:', {k: f'{v:.2e}' for k, v in worst.items()})
+    assert max(worst.values()) < 1e-4, worst
+
+
+def test_stress_100k_parity_mode_tables_equal_reference():
+    """Parity mode at stress size: level-0 subsampling and the level-0 / level-1 tables equal the unmodified reference C++
+    element for element (100k-point KD-trees, libstdc++ order of 27k-voxel maps)."""
+    from oracle import native
+    from regtr_amd import cpp_wrappers
+    if not native.have_ref():
+        pytest.skip('oracle/_ref not present')
+    src, tgt = _pair()
+    pts = np.concatenate([src, tgt]); lens = np.array([len(src), len(tgt)], np.int32)
+    prev = cpp_wrappers.reference_order(True)
+    try:
+        sub, sl = cpp_wrappers.grid_subsampling.subsample_batch(pts, lens, sampleDl=0.05)
+        rsub, rsl = native.ref_subsample_batch(pts, lens, 0.05)
+        assert np.array_equal(sl, rsl) and np.array_equal(sub.view(np.uint32), rsub.view(np.uint32))
+        assert np.array_equal(cpp_wrappers.radius_neighbors.batch_query(pts, pts, lens, lens, radius=0.0625),
+                              native.ref_batch_query(pts, pts, lens, lens, 0.0625))
+        assert np.array_equal(cpp_wrappers.radius_neighbors.batch_query(sub, pts, sl, lens, radius=0.0625),
+                              native.ref_batch_query(sub, pts, sl, lens, 0.0625))
+    finally:
+        cpp_wrappers.reference_order(prev)

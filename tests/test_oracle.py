@@ -98,3 +98,17 @@ def test_reference_order_pyramid_matches_golden():
         assert np.array_equal(pts.view(np.uint32), g[f'points_{l}'].view(np.uint32))
         assert np.array_equal(lens, g[f'lens_{l}'])
         dl *= 2
+
+
+def test_compute_overlaps_restatement_vs_reference_golden():
+    """oracle compute_overlaps (kpconv.py:540-566) == the reference's own function run on the reference Preprocessor's pyramid
+    (tests/golden/overlaps_3dmatch_crop.npz, made by oracle/make_golden.py)."""
+    if not native.have_ref():
+        pytest.skip('needs oracle/_ref for the reference row order')
+    g = gold('overlaps_3dmatch_crop')
+    cfg = load_cfg('3dmatch')
+    meta = regtr_ref.preprocess([g['src'], g['tgt']], cfg, use_ref_cpp=True)
+    pyr = regtr_ref.compute_overlaps({'src_overlap': [torch.from_numpy(g['src_overlap'])], 'tgt_overlap': [torch.from_numpy(g['tgt_overlap'])],
+                                      'kpconv_meta': meta})
+    for p in range(4):
+        assert np.allclose(pyr[f'pyr_{p}'].numpy(), g[f'pyr_{p}'], rtol=0, atol=1e-7, equal_nan=True), p
