@@ -31,9 +31,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFS = 2500.0   # dense bf16 MFMA peak (same guide); the f32-input MFMA peak is 157.3
 
 
-from regtr_amd.synthetic import synth_pair  # noqa: E402  (synthetic 3DMatch-like pairs)
+from regtr_amd.synthetic import synth_modelnet_pair, synth_pair  # noqa: E402  
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -70,6 +71,29 @@ def measure_kpconv_roofline(model, batch, reps=5):
         'alg_bytes_per_step': alg / reps, 'alg_gather_bytes_per_step': alg_gather / reps,
         'gather_s_per_step': t_gather / reps, 'gemm_s_per_step': t_gemm / reps,
     }
+
+
+def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
+    """Times every attention-core launch (k_mha_fwd*) with HIP events on its stream during real forwards.  Algorithmic flops
+    (SURVEY.md 8d): per layer and pair 4 d (Ns^2 + Nt^2 + 2 Ns Nt) -- QK^T and AV of the two self- and the two
+    cross-attentions, d = d_embed."""
+    from regtr_amd import ops
+    records = []
+    ops.mha_records = records
+    try:
+        for _ in range(reps):
+            b = {'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])}
+            model(b)
+        torch.cuda.synchronize()
+    finally:
+        ops.mha_records = None
+    lens = b['kpconv_meta']['_lens_host'][-1]
+    B = len(lens) // 2
+    flops_fwd = n_layers * sum(4.0 * d_embed * (lens[i] ** 2 + lens[B + i] ** 2 + 2.0 * lens[i] * lens[B + i]) for i in range(B))
+    t = sum(e0.elapsed_time(e1) for e0, e1 in records) * 1e-3
+    return {'kernel': 'k_mha_fwd', 'launches_per_step': len(records) // reps, 'avg_launch_us': t / len(records) * 1e6,
+            'alg_flops_per_step': flops_fwd, 'attention_s_per_step': t / reps, 'achieved_TFs': flops_fwd * reps / t / 1e12,
+            'tokens_per_cloud_mean': float(np.mean(lens))}
 
 
 def pmc_traffic(pairs, points, shuffle, detail):
@@ -132,37 +156,57 @@ def pick_cpu_threads(run_probe):
     return best, cores
 
 
-def cpu_baseline(cfg, pairs, max_seconds=20.0):
-    """The CPU oracle port (oracle/regtr_ref.py; preprocessing through the unmodified reference C++ when oracle/_ref is
-    present) on this box's host cores, same workload, bounded sample: whole pairs are timed until `max_seconds` of CPU
-    work have been spent (at least one pair), after warm-up / thread selection on crops of the first pair."""
-    from oracle import native, regtr_ref, seeded_weights
+def cpu_baseline(cfg, pairs, max_seconds=20.0, cfg_name='3dmatch'):
+    """The reference's CPU path on this box's host cores, same workload, bounded sample: whole pairs are timed until
+    `max_seconds` of CPU work have been spent and at least five pairs ran, after warm-up / thread selection on crops of the
+    first pair.  kind 'reference' = the REAL reference RegTR module (imported from /root/reference, its CPU Preprocessor over the
+    unmodified reference C++) where that tree exists; kind 'port' = the CPU oracle restatement pinned to it
+    (oracle/regtr_ref.py; preprocessing through oracle/_ref when present) -- the GPU boxes have no /root/reference."""
+    from oracle import native, ref_loader, regtr_ref, seeded_weights
     from regtr_amd.kernel_points import K015_CENTER
     sd = seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER)
     use_ref = native.have_ref()
+    kind = 'port'
+    if ref_loader.available() and use_ref:
+        rcfg = ref_loader.load_cfg(cfg_name)
+        ref_model = ref_loader.build_model(rcfg, 0)
+        ref_model.load_state_dict(sd, strict=True)
+        kind = 'reference'
+
+        def forward(s, t, timings=None):
+            t0 = time.perf_counter()
+            ref_model({'src_xyz': [torch.from_numpy(s)], 'tgt_xyz': [torch.from_numpy(t)]})
+            if timings is not None:
+                timings.append((float('nan'), float('nan'), time.perf_counter() - t0))
+    else:
+        def forward(s, t, timings=None):
+            regtr_ref.regtr_forward(sd, cfg, [s], [t], use_ref_cpp=use_ref, timings=timings)
     times, stages = [], []
     with torch.no_grad():
         s0, t0_ = pairs[0]
         # rows are spatially ordered, so a prefix is a compact crop
-        crop = lambda f: regtr_ref.regtr_forward(sd, cfg, [s0[:len(s0) // f]], [t0_[:len(t0_) // f]], use_ref_cpp=use_ref)
+        crop = lambda f: forward(s0[:max(len(s0) // f, 64)], t0_[:max(len(t0_) // f, 64)])
         crop(16)                                                                      # warm-up
         threads, cores = pick_cpu_threads(lambda: crop(4))
         t_start = time.perf_counter()
         for s, t in pairs:
             tm = []
             t0 = time.perf_counter()
-            regtr_ref.regtr_forward(sd, cfg, [s], [t], use_ref_cpp=use_ref, timings=tm)
+            forward(s, t, tm)
             times.append(time.perf_counter() - t0); stages.append(tm[0])
-            if time.perf_counter() - t_start > max_seconds:
+            if time.perf_counter() - t_start > max_seconds and len(times) >= 5:
                 break
     med = float(np.median(times))
     st = np.median(np.array(stages), axis=0)
-    return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{len(times)} timed pair(s) (bounded to ~{max_seconds:.0f} s of CPU work) after warm-up, same synthetic '
-                      f'~{len(pairs[0][0])}-pt pairs, fp32 torch CPU restatement of the reference modules on {threads} threads '
-                      f'(fastest of 1, 1/4, 1/2, all of the {cores} usable cores on a 1/4-crop probe; os.cpu_count()={os.cpu_count()}); preprocessing by '
-                      f'{"the unmodified reference C++ (oracle/_ref)" if use_ref else "the C++ oracle restatement"}; '
-                      f'median s/pair {med:.2f} = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'}
+    what = ('the REAL reference RegTR module (src/models/regtr.py) with its CPU Preprocessor over the unmodified reference C++' if kind == 'reference'
+            else 'fp32 torch CPU restatement of the reference modules; preprocessing by ' +
+                 ('the unmodified reference C++ (oracle/_ref)' if use_ref else 'the C++ oracle restatement'))
+    split = '' if kind == 'reference' else f' = preprocess {st[0]:.2f} + encoder {st[1]:.2f} + attention/head/pose {st[2]:.2f}'
+    return {'value': 1.0 / med, 'unit': 'pairs/s', 'cores': threads, 'kind': kind,
+            'sample': f'{len(times)} timed pair(s) (bounded to ~{max_seconds:.0f} s of CPU work, >= 5 pairs) after warm-up, same synthetic '
+                      f'~{len(pairs[0][0])}-pt pairs, {what}, on {threads} threads '
+                      f'(fastest of 1, 1/4, 1/2, all of the {cores} usable cores on a 1/4-crop probe; os.cpu_count()={os.cpu_count()}); '
+                      f'median s/pair {med:.3f}{split}'}
 
 
 def run_stub(args, rank, world, dist):
@@ -194,13 +238,26 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--pairs', type=int, default=64, help='pairs per step per GPU (one forward; pairs are independent, 288 GB of HBM holds far more)')
+    ap.add_argument('--config', choices=['3dmatch', 'modelnet'], default='3dmatch',
+                    help='3dmatch = BASELINE configs[2] (the headline metric); modelnet = configs[1] (ModelNet-size pairs, bf16 cross-encoder)')
+    ap.add_argument('--dtype', choices=['fp32', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
+    ap.add_argument('--cpu-baseline-only', action='store_true',
+                    help='no GPU needed: time only the CPU baseline leg on the synthetic workload and print it (where /root/reference '
+                         'exists this times the REAL reference module, kind "reference")')
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        from regtr_amd.config import load_config
+        cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
+        gen = (lambda i: synth_modelnet_pair(i)) if args.config == 'modelnet' else (lambda i: synth_pair(i, args.points, args.shuffle))
+        print(json.dumps({'cpu_baseline': cpu_baseline(cfg, [gen(i) for i in range(6 if args.config == '3dmatch' else 24)],
+                                                       cfg_name=args.config), 'config': args.config}))
+        return
 
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
@@ -237,11 +294,18 @@ def main():
 
     from regtr_amd import RegTR, load_config
     from regtr_amd.distributed import gather_poses
-    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
+    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
+    dtype = args.dtype or ('bf16' if args.config == 'modelnet' else 'fp32')
+    cfg.update({'compute_dtype': dtype})
     torch.manual_seed(0); np.random.seed(0)
     model = RegTR(cfg).to(dev).eval()
 
-    pairs = [synth_pair(rank * 100003 + i, args.points, args.shuffle) for i in range(args.pairs)]
+    n_pairs = args.pairs if args.pairs else (256 if args.config == 'modelnet' else 64)
+    args.pairs = n_pairs
+    if args.config == 'modelnet':
+        pairs = [synth_modelnet_pair(rank * 100003 + i) for i in range(n_pairs)]
+    else:
+        pairs = [synth_pair(rank * 100003 + i, args.points, args.shuffle) for i in range(n_pairs)]
     batch = {'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in pairs],
              'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in pairs]}
     pair_ids = torch.arange(args.pairs, device=dev, dtype=torch.int32) + rank * args.pairs
@@ -271,22 +335,51 @@ def main():
 
     if rank == 0:
         total_pairs = world * args.steps * args.pairs
+        mean_pts = [int(np.mean([len(s) for s, _ in pairs])), int(np.mean([len(t) for _, t in pairs]))]
+        if args.config == 'modelnet':
+            metric = f'point-cloud pairs/sec (ModelNet ~{mean_pts[0]} pts)'
+            workload = 'BASELINE configs[1]: ModelNet40-benchmark-size pairs, 6-layer cross-attn in ' + dtype
+        else:
+            metric = 'point-cloud pairs/sec (3DMatch ~20k pts)'
+            workload = 'BASELINE configs[2]: 3DMatch-size pairs, full KPConv encoder + 6-layer cross-attn + SVD'
+            if args.points != 20000:
+                workload = f'BASELINE configs[4]-style stress: ~{args.points}-point clouds, conf/3dmatch.yaml pipeline'
         res = {
-            'metric': 'point-cloud pairs/sec (3DMatch ~20k pts)', 'value': total_pairs / elapsed, 'unit': 'pairs/s',
+            'metric': metric, 'value': total_pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[2]: 3DMatch-size pairs, full KPConv encoder + 6-layer cross-attn + SVD',
-                       'pairs_per_step_per_gpu': args.pairs,
-                       'points_per_cloud': [int(np.mean([len(s) for s, _ in pairs])), int(np.mean([len(t) for _, t in pairs]))],
-                       'arch': 'conf/3dmatch.yaml, random-init weights', 'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
+            'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
+                       'arch': f'conf/{args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
+                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
         }
         if not args.no_roofline:
             r = measure_kpconv_roofline(model, batch)
-            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r)
-            res['roofline'] = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
+            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r) if args.config == '3dmatch' else None
+            gather = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
+            a = measure_attention(model, batch, cfg.nhead, cfg.d_embed, cfg.num_encoder_layers)
+            peak = MFMA_BF16_PEAK_TFS
+            att = {'bound': 'mfma', 'achieved': a['achieved_TFs'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': a['achieved_TFs'] / peak,
+                   'traffic': None, 'detail': dict(a, operands={'fp32': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
+                                                               'bf16': 'plain bf16 (1 MFMA per product)'}[dtype],
+                                                   peak_note='dense bf16 MFMA peak; the split mode issues 6x the algorithmic flops')}
+            # the dominant kernel of the configuration leads: KPConv gather (HBM) for 3DMatch-size pairs, attention (MFMA) for ModelNet
+            res['roofline'] = att if args.config == 'modelnet' else gather
+            res['roofline_secondary'] = gather if args.config == 'modelnet' else att
+        if dtype != 'fp32':
+            # reduced-precision error, reported next to the number (parity is gated in fp32): same batch, float32-grade model
+            cfg32 = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
+            m32 = RegTR(cfg32).to(dev).eval()
+            m32.load_state_dict(model.state_dict())
+            sub = {'src_xyz': list(batch['src_xyz'][:16]), 'tgt_xyz': list(batch['tgt_xyz'][:16])}
+            o32 = m32(dict(sub)); olo = model(dict(sub))
+            nb = len(sub['src_xyz'])
+            res['reduced_precision_error'] = {
+                'vs': 'float32-grade run of the same weights / pairs', 'pairs': nb,
+                'max_abs_correspondence': max(float((olo['src_kp_warped'][b] - o32['src_kp_warped'][b]).abs().max()) for b in range(nb)),
+                'max_abs_pose': float((olo['pose'] - o32['pose']).abs().max())}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
-            res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(4)])
+            res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(6 if args.config == '3dmatch' else 24)], cfg_name=args.config)
         print(json.dumps(res))
     if dist:
         dist.barrier()

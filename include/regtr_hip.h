@@ -168,7 +168,10 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, void* stream);
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, void* stream);
+/* n_planes: 3 = the float32-grade six-term product (default everywhere); 2 = three leading terms (a0 w0 + a0 w1 + a1 w0,
+ * ~2^-16 relative per product); 1 = plain bf16 operands with float32 accumulation (cfg.compute_dtype 'bf16').  1 and 2 do not
+ * combine with a_stats / stat_partial (the KPConv encoder always runs float32-grade). */
 /* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
  * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud
  * offsets of C's rows; then regtr_instnorm_finalize_tiles(stat_partial, seg_off, n_clouds, N, R, eps, stats) yields the

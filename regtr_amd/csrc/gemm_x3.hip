@@ -70,15 +70,17 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsign
     p2 = x3_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
 }
 
-template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT>      // MW x NW waves, wave tile (32 WM) x (32 WN)
+// NP = bf16 planes per operand: 3 = float32-grade (six MFMA terms, the default); 2 = the three leading terms a0 w0 + a0 w1 +
+// a1 w0 (relative error ~2^-16 per product); 1 = plain bf16 operands (cfg.compute_dtype 'bf16').
+template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT, int NP = 3>      // MW x NW waves, wave tile (32 WM) x (32 WN)
 __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x3(X3Args g)
 {
     constexpr int NT = 64 * MW * NW, RPP = NT / 8; // threads; A rows staged per pass (8 float4 per row)
     constexpr int BM = 32 * WM * MW, BN = 32 * WN * NW;
     constexpr int AV = BM / RPP;                  // float4 of A per thread per tile
-    constexpr int NQ = 3 * BN / (16 * MW * NW);   // LDS-DMA instructions (1 KiB each) per wave per tile
-    static_assert(BM % RPP == 0 && (3 * BN) % (16 * MW * NW) == 0, "tile must split evenly over the waves");
-    constexpr int A_BYTES = 3 * BM * XROW, B_BYTES = 3 * BN * XROW;
+    constexpr int NQ = NP * BN / (16 * MW * NW);  // LDS-DMA instructions (1 KiB each) per wave per tile
+    static_assert(BM % RPP == 0 && (NP * BN) % (16 * MW * NW) == 0, "tile must split evenly over the waves");
+    constexpr int A_BYTES = NP * BM * XROW, B_BYTES = NP * BN * XROW;
     __shared__ __align__(1024) unsigned char As[A_BYTES];
     __shared__ __align__(1024) unsigned char Bs0[B_BYTES];     // two SEPARATE objects: the compiler can then tell that the
     __shared__ __align__(1024) unsigned char Bs1[B_BYTES];     // DMA into one does not alias fragment reads of the other
@@ -175,8 +177,8 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
             x3_split2(v.z, v.w, p0b, p1b, p2b);
             unsigned char* dst = As + a_st_off + i * RPP * XROW;
             *(uint2*)(dst) = make_uint2(p0a, p0b);
-            *(uint2*)(dst + BM * XROW) = make_uint2(p1a, p1b);
-            *(uint2*)(dst + 2 * BM * XROW) = make_uint2(p2a, p2b);
+            if (NP > 1) *(uint2*)(dst + BM * XROW) = make_uint2(p1a, p1b);
+            if (NP > 2) *(uint2*)(dst + 2 * BM * XROW) = make_uint2(p2a, p2b);
         }
     };
     // ---- B streaming: DMA q of this wave fills LDS bytes [(wave NQ + q) 1024, +1024) of the buffer; lane i is slot
@@ -210,23 +212,25 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     auto compute = [&](const unsigned char* Bb) {
 #pragma unroll
         for (int ks = 0; ks < XBK / 16; ks++) {
-            bf16x8 fa[WM][3], fb[WN][3];
+            bf16x8 fa[WM][NP], fb[WN][NP];
 #pragma unroll
             for (int i = 0; i < WM; i++)
 #pragma unroll
-                for (int p = 0; p < 3; p++)
+                for (int p = 0; p < NP; p++)
                     fa[i][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(As + (p * BM + (wm * WM + i) * 32) * XROW + f_off[ks]));
 #pragma unroll
             for (int j = 0; j < WN; j++)
 #pragma unroll
-                for (int p = 0; p < 3; p++)
+                for (int p = 0; p < NP; p++)
                     fb[j][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + (p * BN + (wn * WN + j) * 32) * XROW + f_off[ks]));
             // six terms, smallest first; the (i, j) loops sit inside so consecutive MFMAs hit different accumulators
 #define X3_TERM(PA, PB)                                                                                             \
             _Pragma("unroll") for (int i = 0; i < WM; i++)                                                           \
                 _Pragma("unroll") for (int j = 0; j < WN; j++)                                                       \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
-            X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) X3_TERM(1, 0) X3_TERM(0, 1) X3_TERM(0, 0)
+            if (NP == 3) { X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) }
+            if (NP >= 2) { X3_TERM((NP >= 2 ? 1 : 0), 0) X3_TERM(0, (NP >= 2 ? 1 : 0)) }
+            X3_TERM(0, 0)
 #undef X3_TERM
         }
     };
@@ -440,9 +444,10 @@ int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, void* stream)
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, void* stream)
 {
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
+    if (n_planes < 1 || n_planes > 3 || (n_planes != 3 && (a_stats || stat_partial))) return RG_ERR_ARG;
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
@@ -457,7 +462,9 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
     dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * (N / bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
 #define X3_LAUNCH(MW_, NW_, WM_, WN_) do { \
-        if (a_stats) { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, true, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+        if (n_planes == 1) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+        else if (n_planes == 2) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 2><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+        else if (a_stats) { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, true, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                        else k_gemm_x3<MW_, NW_, WM_, WN_, true, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \
         else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)

@@ -111,12 +111,13 @@ class SplitWeight:
 
 
 def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1,
-         want_stats=None, eps=1e-5):
+         want_stats=None, eps=1e-5, planes=3):
     """a (M,K) @ b with the fused epilogue of regtr_gemm_f32 / regtr_gemm_x3.  b: a (K,N) float32 tensor (exact-f32 MFMA
     kernel) or a SplitWeight (bf16x3 split kernel when the shape allows).  `a` may be a row-strided view.
     a_stats (n_seg,K,2) + a_seg_off: A is read as LeakyReLU(InstanceNorm(a)) (per-cloud stats) on the fly.
     want_stats = (seg_off, max_len): also return the per-cloud InstanceNorm (mean, rstd) table (n_clouds,N,2) of the
-    result -- from the GEMM epilogue when the kernel supports it, else by a pass over the result."""
+    result -- from the GEMM epilogue when the kernel supports it, else by a pass over the result.
+    planes: bf16 planes per operand on the split kernel -- 3 float32-grade (default), 2 three-term split, 1 plain bf16."""
     L = _lib.lib()
     M, K = a.shape
     sw = b if isinstance(b, SplitWeight) else None
@@ -142,7 +143,7 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         check(L.regtr_gemm_x3(raw(a), lda, bptr(sw.planes), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
-                              stream()), 'regtr_gemm_x3')
+                              int(planes), stream()), 'regtr_gemm_x3')
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
             check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
@@ -281,10 +282,20 @@ def mha(q, k, v, seg_off, kv_of, max_len, n_heads, precision=0):
     N, E = q.shape
     hd = E // n_heads
     out = torch.empty((N, E), dtype=torch.float32, device=q.device)
+    rec = mha_records
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.lib().regtr_mha_fwd(raw(q), q.stride(0), raw(k), k.stride(0), raw(v), v.stride(0),
                                    ptr(out), E, iptr(seg_off), iptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
                                    1.0 / math.sqrt(hd), int(precision), stream()), 'regtr_mha_fwd')
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
     return out
+
+
+mha_records = None      # bench.py: list to time every attention-core launch (HIP events on the launch stream)
 
 
 def attn_xyz(q, k, xyz, seg_off, kv_of, max_len):

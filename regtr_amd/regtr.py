@@ -113,6 +113,14 @@ class RegTR(nn.Module):
             normalize_before=cfg.pre_norm, sa_val_has_pos_emb=cfg.sa_val_has_pos_emb,
             ca_val_has_pos_emb=cfg.ca_val_has_pos_emb, attention_type=cfg.attention_type)
         encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
+        # cfg.compute_dtype (not a reference key): 'fp32' (default) = float32-grade everywhere (bf16x3 split MFMA); 'bf16' =
+        # plain bf16 operands with float32 accumulation / softmax in the cross-encoder's linears and attention core
+        # (BASELINE configs[1]; the KPConv encoder, head and pose stay float32-grade); 'bf16x2' = three-term split linears.
+        dt = cfg.get('compute_dtype', 'fp32')
+        if dt not in ('fp32', 'bf16', 'bf16x2'):
+            raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, bf16 or bf16x2')
+        encoder_layer.gemm_planes = {'fp32': 3, 'bf16x2': 2, 'bf16': 1}[dt]
+        encoder_layer.attn_precision = 1 if dt == 'bf16' else 0
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)
         if cfg.get('direct_regress_coor', False):                                 # :68-73

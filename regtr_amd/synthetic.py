@@ -82,3 +82,41 @@ def synth_pair(pair_id, pts_per_cloud=20000, shuffle=False, return_pose=False):
     if return_pose:
         return src.astype(np.float32), tgt.astype(np.float32), np.concatenate([R, t[:, None]], 1).astype(np.float32)
     return src.astype(np.float32), tgt.astype(np.float32)
+
+
+def synth_modelnet_pair(pair_id, num_points=1024, keep=0.7, return_pose=False):
+    """ModelNet40-benchmark-sized pair (conf/modelnet.yaml: num_points 1024, partial [0.7, 0.7],
+    rot_mag 45, trans_mag 0.5): points on a random union of 3-6 ellipsoid / box surfaces inside the unit cube, two
+    independent 70 % half-space crops (~717 points each), the target moved by a random SE(3) and both jittered by
+    N(0, 0.01) clipped at 0.05.  Deterministic in pair_id."""
+    rng = np.random.default_rng(7000 + pair_id)
+    parts = []
+    n_prim = int(rng.integers(3, 7))
+    per = 4 * num_points // n_prim + 1
+    for _ in range(n_prim):
+        c = rng.uniform(-0.45, 0.45, 3)
+        r = rng.uniform(0.15, 0.5, 3)
+        if rng.random() < 0.5:                                  # ellipsoid surface
+            v = rng.standard_normal((per, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+            parts.append(c + v * r)
+        else:                                                   # box surface
+            p = rng.uniform(-1, 1, (per, 3))
+            ax = rng.integers(0, 3, per)
+            p[np.arange(per), ax] = np.sign(rng.standard_normal(per))
+            parts.append(c + p * r)
+    obj = np.concatenate(parts)
+    obj = obj / np.abs(obj).max()                               # unit scale
+    obj = obj[rng.permutation(len(obj))]
+
+    def crop(points):
+        d = rng.standard_normal(3); d /= np.linalg.norm(d)
+        proj = points @ d
+        return points[proj > np.quantile(proj, 1.0 - keep)]
+    src = crop(obj[rng.choice(len(obj), num_points, replace=False)])
+    tgt = crop(obj[rng.choice(len(obj), num_points, replace=False)])
+    R, t = random_se3(rng)
+    jit = lambda p: p + np.clip(rng.normal(scale=0.01, size=p.shape), -0.05, 0.05)
+    src, tgt = jit(src), jit(tgt @ R.T + t)
+    if return_pose:
+        return src.astype(np.float32), tgt.astype(np.float32), np.concatenate([R, t[:, None]], 1).astype(np.float32)
+    return src.astype(np.float32), tgt.astype(np.float32)

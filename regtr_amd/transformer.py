@@ -36,11 +36,17 @@ class TransformerCrossEncoderLayer(nn.Module):
         self.nhead, self.d_model, self.normalize_before = nhead, d_model, normalize_before
         self.sa_val_has_pos_emb, self.ca_val_has_pos_emb = sa_val_has_pos_emb, ca_val_has_pos_emb
         self._cache = {}
+        # arithmetic of the dense kernels (set by RegTR from cfg.compute_dtype): bf16 planes per GEMM operand (3 = float32-grade)
+        # and the attention core's precision code (ops.mha)
+        self.gemm_planes, self.attn_precision = 3, 0
 
     def _wt(self, name, param, rows=None):
         """The weight (optionally a row block of it: in_proj packs q, k, v) prepared once for the dense kernels."""
         key = name if rows is None else (name, rows)
         return _prepared(self._cache, key, param, lambda w: ops.SplitWeight(w if rows is None else w[rows[0]:rows[1]], 'nk'))
+
+    def _gemm(self, a, w, **kw):
+        return ops.gemm(a, w, planes=self.gemm_planes, **kw)
 
     def _attention(self, attn, tag, x, norm, pe, val_has_pe, seg_off, kv_of, max_len):
         """x + out_proj( MHA(q = k = LN(x) + pe, v = LN(x) [+ pe]) ) for every token (transformers.py:194-229)."""
@@ -48,19 +54,19 @@ class TransformerCrossEncoderLayer(nn.Module):
         b_in = attn.in_proj_bias.detach()
         if pe is None:
             x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), eps=norm.eps)
-            qkv = ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
+            qkv = self._gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
         elif val_has_pe:
             x2p = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps)
-            qkv = ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
+            qkv = self._gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
         else:
             x2p, x2 = ops.layernorm(x, norm.weight.detach(), norm.bias.detach(), add=pe, eps=norm.eps, want_plain=True)
             qkv = torch.empty((x.shape[0], 3 * D), dtype=torch.float32, device=x.device)
             b_qk = _prepared(self._cache, tag + '_bqk', attn.in_proj_bias, lambda b: b[:2 * D].contiguous())
             b_v = _prepared(self._cache, tag + '_bv', attn.in_proj_bias, lambda b: b[2 * D:].contiguous())
-            ops.gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
-            ops.gemm(x2, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
-        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
-        return ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
+            self._gemm(x2p, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
+            self._gemm(x2, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
+        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead, self.attn_precision)
+        return self._gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
 
     def _attention_post(self, attn, tag, x, norm, pe, val_has_pe, seg_off, kv_of, max_len):
         """LN( x + out_proj( MHA(q = k = x + pe, v = x [+ pe]) ) ) for every token (forward_post, transformers.py:131-166)."""
@@ -68,15 +74,15 @@ class TransformerCrossEncoderLayer(nn.Module):
         b_in = attn.in_proj_bias.detach()
         xp = x if pe is None else ops.add(x, pe)
         if pe is None or val_has_pe:
-            qkv = ops.gemm(xp, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
+            qkv = self._gemm(xp, self._wt(tag + '_in', attn.in_proj_weight), bias=b_in)
         else:
             qkv = torch.empty((x.shape[0], 3 * D), dtype=torch.float32, device=x.device)
             b_qk = _prepared(self._cache, tag + '_bqk', attn.in_proj_bias, lambda b: b[:2 * D].contiguous())
             b_v = _prepared(self._cache, tag + '_bv', attn.in_proj_bias, lambda b: b[2 * D:].contiguous())
-            ops.gemm(xp, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
-            ops.gemm(x, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
-        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead)
-        y = ops.gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
+            self._gemm(xp, self._wt(tag + '_in', attn.in_proj_weight, (0, 2 * D)), bias=b_qk, out=qkv[:, :2 * D])
+            self._gemm(x, self._wt(tag + '_in', attn.in_proj_weight, (2 * D, 3 * D)), bias=b_v, out=qkv[:, 2 * D:])
+        att = ops.mha(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], seg_off, kv_of, max_len, self.nhead, self.attn_precision)
+        y = self._gemm(att, self._wt(tag + '_out', attn.out_proj.weight), bias=attn.out_proj.bias.detach(), residual=x)
         return ops.layernorm(y, norm.weight.detach(), norm.bias.detach(), eps=norm.eps)
 
     def forward_post(self, x, pe, seg_off, kv_self, kv_cross, max_len):
@@ -84,8 +90,8 @@ class TransformerCrossEncoderLayer(nn.Module):
         x = self._attention_post(self.self_attn, 'sa', x, self.norm1, pe, self.sa_val_has_pos_emb, seg_off, kv_self, max_len)
         x = self._attention_post(self.multihead_attn, 'ca', x, self.norm2, pe, self.ca_val_has_pos_emb, seg_off, kv_cross,
                                  max_len)
-        h = ops.gemm(x, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
-        y = ops.gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)       # :168-170
+        h = self._gemm(x, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
+        y = self._gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)       # :168-170
         return ops.layernorm(y, self.norm3.weight.detach(), self.norm3.bias.detach(), eps=self.norm3.eps)
 
     def forward(self, x, pe, seg_off, kv_self, kv_cross, max_len):
@@ -96,8 +102,8 @@ class TransformerCrossEncoderLayer(nn.Module):
         x = self._attention(self.multihead_attn, 'ca', x, self.norm2, pe, self.ca_val_has_pos_emb, seg_off, kv_cross,
                             max_len)
         x2 = ops.layernorm(x, self.norm3.weight.detach(), self.norm3.bias.detach(), eps=self.norm3.eps)   # :232
-        h = ops.gemm(x2, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
-        return ops.gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)  # :233-238
+        h = self._gemm(x2, self._wt('l1', self.linear1.weight), bias=self.linear1.bias.detach(), relu=True)
+        return self._gemm(h, self._wt('l2', self.linear2.weight), bias=self.linear2.bias.detach(), residual=x)  # :233-238
 
 
 class TransformerCrossEncoder(nn.Module):

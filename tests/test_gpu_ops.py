@@ -373,24 +373,51 @@ def test_layernorm_posemb_vs_oracle():
     assert (pe - regtr_ref.pos_embed_sine(xyz, 256, 1.0)).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900]])
-def test_mha_vs_oracle(lens):
-    """self- and cross-attention cores on packed ragged clouds vs the plain softmax(QK^T)V restatement."""
+@pytest.mark.parametrize('precision,tol', [(0, 2e-5), (2, 2e-5), (1, 6e-2)])
+@pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900], [130, 0, 5, 129]])
+def test_mha_vs_oracle(lens, precision, tol):
+    """self- and cross-attention cores on packed ragged clouds vs the plain softmax(QK^T)V restatement in float64:
+    precision 0 (bf16x3 split MFMA, the default) and 2 (exact-f32 MFMA) at float32 accuracy, 1 (plain bf16 operands) at
+    bf16 accuracy; an empty partner cloud gives zeros."""
     ops = _ops()
     g = torch.Generator().manual_seed(sum(lens))
     N, E, H = sum(lens), 256, 8
     qkv = torch.randn(N, 3 * E, generator=g) * 1.5
     seg = np.concatenate([[0], np.cumsum(lens)])
     B = len(lens) // 2
+    worst = 0.0
     for kv in (list(range(2 * B)), list(range(B, 2 * B)) + list(range(B))):
         out = ops.mha(qkv.cuda()[:, :E], qkv.cuda()[:, E:2 * E], qkv.cuda()[:, 2 * E:], seg_of(lens),
-                      torch.tensor(kv, dtype=torch.int32).cuda(), max(lens), H).cpu()
+                      torch.tensor(kv, dtype=torch.int32).cuda(), max(lens), H, precision).cpu()
         for c in range(2 * B):
+            if seg[c + 1] == seg[c]:
+                continue
+            if seg[kv[c] + 1] == seg[kv[c]]:
+                assert out[seg[c]:seg[c + 1]].abs().max() == 0
+                continue
             q = qkv[seg[c]:seg[c + 1], :E].view(-1, H, 32).transpose(0, 1) / math.sqrt(32)
             k = qkv[seg[kv[c]]:seg[kv[c] + 1], E:2 * E].view(-1, H, 32).transpose(0, 1)
             v = qkv[seg[kv[c]]:seg[kv[c] + 1], 2 * E:].view(-1, H, 32).transpose(0, 1)
             ref = (torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()).transpose(0, 1).reshape(-1, E)
-            assert (out[seg[c]:seg[c + 1]].double() - ref).abs().max() < 2e-5
+            worst = max(worst, (out[seg[c]:seg[c + 1]].double() - ref).abs().max().item())
+    print(f'mha precision {precision} lens {lens}: max abs err {worst:.2e}')
+    assert worst < tol
+
+
+@pytest.mark.parametrize('planes,tol', [(3, 3e-6), (2, 2e-4), (1, 2e-2)])
+def test_gemm_x3_plane_count(planes, tol, x3_forced):
+    """regtr_gemm_x3 with 3 (float32-grade), 2 (three-term) and 1 (plain bf16) planes per operand vs float64, relative to the
+    result's scale -- the measured accuracy classes behind cfg.compute_dtype."""
+    ops = x3_forced
+    g = torch.Generator().manual_seed(planes)
+    a = torch.randn(3000, 256, generator=g).cuda()
+    w = (torch.randn(1024, 256, generator=g) / 16).cuda()
+    bias = torch.randn(1024, generator=g).cuda()
+    out = ops.gemm(a, ops.SplitWeight(w, 'nk'), bias=bias, relu=True, planes=planes).cpu().double()
+    ref = torch.relu(a.cpu().double() @ w.cpu().double().t() + bias.cpu().double())
+    err = ((out - ref).abs().max() / ref.abs().max()).item()
+    print(f'gemm_x3 planes {planes}: max rel err {err:.2e}')
+    assert err < tol
 
 
 def test_procrustes_vs_oracle():
