@@ -77,6 +77,12 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
                        int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
                        int* out_count, int* out_max_count, void* stream);
 
+/* The same table for the grid's OWN supports as queries (every conv table of the pyramid): a cell-centric kernel -- one wave
+ * per occupied cell stages the 27 neighbouring runs once in LDS and answers all of the cell's queries from there.  out_idx
+ * [ns_cap, K] is indexed by the original support row; results are identical to regtr_radius_query(s_xyz, s_seg_off, ...). */
+int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, const void* grid_ws,
+                            size_t ws_bytes, int* out_idx, int* out_count, int* out_max_count, void* stream);
+
 /* ---- ground-truth overlap (training / validation side) ------------------------------------------- */
 
 /* utils/pointcloud.py:8-65 compute_overlap: index of the NEAREST support of the query's cloud with d2 < radius^2, distances

@@ -478,16 +478,29 @@ struct GridView {
 constexpr int QUERY_WAVES = 4;  // queries in flight per 256-thread workgroup
 
 // rank of every list entry among the n keys (keys are unique: the index is part of the key)
-// list lives in LDS; entries e = lane, lane+64, ...
+// list lives in LDS (16-byte aligned, room for n + 7 entries); entries e = lane, lane+64, ...
+// The keys are read EIGHT per step as four independent 16-byte broadcast reads with one wait: a one-key-per-iteration loop
+// (ds_read_b64, s_waitcnt lgkmcnt(0), compare) exposes a full LDS round trip per key -- ~100 cycles x ~30 keys per query was
+// most of the radius search's time.  The tail is padded with +inf keys, which rank below nothing.
 template <typename F>
-__device__ __forceinline__ void for_each_ranked(const uint64_t* list, int n, F&& f)
+__device__ __forceinline__ void for_each_ranked(uint64_t* list, int n, F&& f)
 {
     const int lane = rg_lane();
+    const int np = (n + 7) & ~7;
+    if (lane < np - n) list[n + lane] = ~0ULL;
+    __builtin_amdgcn_wave_barrier();
     for (int e0 = 0; e0 < n; e0 += RG_WAVE) {
         const int e = e0 + lane;
         const uint64_t mine = e < n ? list[e] : ~0ULL;
         int rank = 0;
-        for (int j = 0; j < n; j++) rank += list[j] < mine ? 1 : 0;  // broadcast LDS read
+        for (int j = 0; j < np; j += 8) {
+            const uint4 a = *(const uint4*)(list + j), b = *(const uint4*)(list + j + 2), c = *(const uint4*)(list + j + 4),
+                        d = *(const uint4*)(list + j + 6);
+#define RG_LT(lo, hi) ((((uint64_t)(hi) << 32) | (lo)) < mine ? 1 : 0)
+            rank += RG_LT(a.x, a.y) + RG_LT(a.z, a.w) + RG_LT(b.x, b.y) + RG_LT(b.z, b.w) + RG_LT(c.x, c.y) + RG_LT(c.z, c.w) +
+                    RG_LT(d.x, d.y) + RG_LT(d.z, d.w);
+#undef RG_LT
+        }
         if (e < n) f(rank, mine);
     }
 }
@@ -592,6 +605,129 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     }
     __builtin_amdgcn_wave_barrier();      // the LDS list is reused by the wave's next query
     }
+}
+
+// ---- self query (queries == the grid's supports: every conv table of the pyramid) -------------------------------------
+// CELL-centric: a wave takes one occupied cell, looks its 27 neighbour cells up ONCE (27 lanes, one round trip), stages their
+// support runs ONCE into LDS (one more round trip), and then answers every query of the cell -- the cell's own points, which
+// are among the staged candidates -- from LDS: distance tests, ballot compaction and the rank sort never touch memory again.
+// The per-query kernel above pays those two dependent round trips per QUERY (its waves spend two thirds of their cycles in
+// s_waitcnt); a cell holds ~6 queries on 3DMatch-density surfaces.  Same float32 arithmetic, same (d2, index) keys, same
+// shrink rule: the tables are bit-identical to k_radius_query's.
+constexpr int SELF_CAND = 256;        // staged candidates per cell (cells whose 27-neighbourhood holds more read from global)
+
+__global__ void __launch_bounds__(QUERY_WAVES * RG_WAVE)
+k_radius_query_self(const int* __restrict__ s_seg_off, int n_clouds, GridView g, float radius, int K, int cap,
+                    int* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max_count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int wave = threadIdx.x >> 6, lane = rg_lane();
+    // per-wave LDS: cand[SELF_CAND] float4 | list[cap] u64 | runs 64 ints
+    unsigned char* base = smem + (size_t)wave * (SELF_CAND * 16 + (size_t)cap * 8 + 256);
+    float4* cand = (float4*)base;
+    uint64_t* list = (uint64_t*)(base + SELF_CAND * 16);
+    int* runs = (int*)(base + SELF_CAND * 16 + (size_t)cap * 8);
+
+    const int ns = s_seg_off[n_clouds];
+    const unsigned T = rg_live_table(ns), mask = T - 1u;
+    const float r2 = __fmul_rn(radius, radius);  // neighbors.cpp:226
+    int wave_max = 0;
+    // grid-stride over chunks of 64 hash slots; the occupied ones of a chunk are handled one after another
+    for (unsigned h0 = (blockIdx.x * QUERY_WAVES + wave) * RG_WAVE; h0 < T; h0 += gridDim.x * QUERY_WAVES * RG_WAVE) {
+        const CellSlot* sl = &g.slots[h0 + lane];
+        const uint4 sa = *(const uint4*)sl;                                  // key | cid | used
+        const uint2 sb = *(const uint2*)((const char*)sl + 16);               // cnt | start
+        unsigned long long occ = __ballot((int)sa.w >= 0 && (int)sb.x > 0);
+        while (occ) {
+            const int src = __ffsll((long long)occ) - 1;
+            occ &= occ - 1;
+            const uint64_t ckey = ((uint64_t)__shfl((int)sa.y, src, RG_WAVE) << 32) | (unsigned)__shfl((int)sa.x, src, RG_WAVE);
+            const int cid = __shfl((int)sa.z, src, RG_WAVE);
+            const int c_cnt = __shfl((int)sb.x, src, RG_WAVE);
+            const int c_start = __shfl((int)sb.y, src, RG_WAVE);
+            const uint64_t m21 = (1ULL << CELL_BITS) - 1;
+            const int64_t cx = (int64_t)(ckey & m21) - CELL_BIAS, cy = (int64_t)((ckey >> CELL_BITS) & m21) - CELL_BIAS,
+                          cz = (int64_t)((ckey >> (2 * CELL_BITS)) & m21) - CELL_BIAS;
+            int my_cnt = 0, my_start = 0;
+            if (lane < 27) {
+                const int dx = lane % 3 - 1, dy = (lane / 3) % 3 - 1, dz = lane / 9 - 1;
+                if (lane == 13) { my_cnt = c_cnt; my_start = c_start; }
+                else slot_find(g.slots, mask, cell_key(cx + dx, cy + dy, cz + dz), cid, my_cnt, my_start);
+            }
+            int inc = my_cnt;
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, true);
+            inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, true);
+            inc += (lane >= 16 && lane < 32) ? __builtin_amdgcn_readlane(inc, 15) : 0;
+            const int total = __builtin_amdgcn_readlane(inc, 26);
+            __builtin_amdgcn_wave_barrier();                                  // previous cell's LDS reads are done
+            if (lane < 27) { runs[lane] = inc - my_cnt; runs[32 + lane] = my_start - (inc - my_cnt); }
+            __builtin_amdgcn_wave_barrier();
+            auto cand_global = [&](int t) -> float4 {
+                int c = 0;
+#pragma unroll
+                for (int step = 16; step > 0; step >>= 1) { const int c2 = c + step; if (c2 < 27 && runs[c2] <= t) c = c2; }
+                return g.sorted[t + runs[32 + c]];
+            };
+            const bool staged = total <= SELF_CAND;                           // wave-uniform
+            if (staged) {
+                for (int t = lane; t < total; t += RG_WAVE) cand[t] = cand_global(t);
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- the cell's queries, one after another (wave-uniform loop)
+            for (int qi = 0; qi < c_cnt; qi++) {
+                // the query is one of the staged candidates (the centre cell is run 13); LDS broadcast instead of a global load
+                const float4 qp = staged ? cand[runs[13] + qi] : g.sorted[c_start + qi];
+                const int q = __float_as_int(qp.w);
+                int n = 0, n_total = 0;
+                for (int t0 = 0; t0 < total; t0 += RG_WAVE) {
+                    const int t = t0 + lane;
+                    bool in = false;
+                    uint64_t key = 0;
+                    if (t < total) {
+                        const float4 sp = staged ? cand[t] : cand_global(t);
+                        const float dx = __fsub_rn(qp.x, sp.x), dy = __fsub_rn(qp.y, sp.y), dz = __fsub_rn(qp.z, sp.z);
+                        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                        in = d2 < r2;
+                        key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(sp.w);
+                    }
+                    const unsigned long long bal = __ballot(in);
+                    if (in) list[n + __popcll(bal & ((1ULL << lane) - 1ULL))] = key;
+                    const int add = __popcll(bal);
+                    n += add;
+                    n_total += add;
+                    __builtin_amdgcn_wave_barrier();
+                    if (n + RG_WAVE > cap) {                                  // keep only the K best so far (as k_radius_query)
+                        uint64_t keep_key[8];
+                        int keep_rank[8];
+#pragma unroll
+                        for (int a = 0; a < 8; a++) {
+                            const int e = a * RG_WAVE + lane;
+                            keep_key[a] = e < n ? list[e] : ~0ULL;
+                            int rank = 0;
+                            if (a * RG_WAVE < n)
+                                for (int j = 0; j < n; j++) rank += list[j] < keep_key[a] ? 1 : 0;
+                            keep_rank[a] = e < n ? rank : INT_MAX;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int a = 0; a < 8; a++)
+                            if (keep_rank[a] < K) list[keep_rank[a]] = keep_key[a];
+                        n = n < K ? n : K;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                int* row = out_idx + (size_t)q * K;
+                for_each_ranked(list, n, [&](int rank, uint64_t k) { if (rank < K) row[rank] = (int)(uint32_t)k; });
+                for (int k = n + lane; k < K; k += RG_WAVE) row[k] = ns;
+                if (lane == 0 && out_count) out_count[q] = n_total;
+                wave_max = n_total > wave_max ? n_total : wave_max;
+                __builtin_amdgcn_wave_barrier();                              // the list is reused by the next query
+            }
+        }
+    }
+    if (out_max_count && lane == 0 && wave_max > 0) atomicMax(out_max_count, wave_max);
 }
 
 // Nearest support inside the ball, in float64 -- the ground-truth overlap test of the reference's data pipeline
@@ -810,6 +946,30 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_cdiv(nq_cap, QUERY_WAVES) : 256 * 64;   // grid-stride inside
     k_radius_query<<<grid, QUERY_WAVES * RG_WAVE, lds, st>>>(
         q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, out_idx, out_count, out_max_count);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// Self query: the rows of EVERY support point of the grid (queries == supports, e.g. the conv tables of the pyramid) by the
+// cell-centric kernel; out_idx [ns_cap, K] indexed by the ORIGINAL support row.  Same results as regtr_radius_query(s_xyz, ...).
+int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, const void* grid_ws,
+                            size_t ws_bytes, int* out_idx, int* out_count, int* out_max_count, void* stream)
+{
+    if (!s_seg_off || !out_idx || !grid_ws || n_clouds < 1 || K < 1 || K > 448 || !(radius > 0.f)) return RG_ERR_ARG;
+    if (ws_bytes < regtr_cellgrid_ws_bytes(ns_cap, n_clouds)) return RG_ERR_WORKSPACE;
+    if (ns_cap <= 0) return RG_OK;
+    GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap);
+    GridView g{b.slots, b.sorted, 1.0 / ((double)radius * (1.0 + 1e-6))};
+    int cap = (2 * K + 63) / 64 * 64;
+    if (cap < 256) cap = 256;
+    if (cap > 512) cap = 512;
+    if (cap < K + RG_WAVE) return RG_ERR_ARG;
+    const size_t lds = (size_t)QUERY_WAVES * (SELF_CAND * 16 + (size_t)cap * 8 + 256);
+    // one wave per 64 hash slots of the LIVE table (<= 3 x ns_cap slots); grid-stride inside
+    const long long chunks = ((long long)b.T + RG_WAVE - 1) / RG_WAVE;
+    const int grid = (int)(rg_cdiv(chunks, QUERY_WAVES) < 256 * 32 ? rg_cdiv(chunks, QUERY_WAVES) : 256 * 32);
+    k_radius_query_self<<<grid, QUERY_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(s_seg_off, n_clouds, g, radius, K, cap, out_idx,
+                                                                                     out_count, out_max_count);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -28,13 +28,16 @@ def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0):
     return out, out_off
 
 
+self_query_kernel = True     # tests / A-B runs: False routes self queries through the per-query kernel as well
+
+
 class CellGrid:
     """Support-point cell grid for one radius; serves any number of radius queries (conv + pool tables of a level)."""
 
     def __init__(self, s_xyz, s_seg_off, ns_cap, radius):
         L = _lib.lib()
         self.n_clouds = s_seg_off.numel() - 1
-        self.s_seg_off, self.ns_cap, self.radius = s_seg_off, int(ns_cap), float(radius)
+        self.s_xyz, self.s_seg_off, self.ns_cap, self.radius = s_xyz, s_seg_off, int(ns_cap), float(radius)
         self.nbytes = L.regtr_cellgrid_ws_bytes(self.ns_cap, self.n_clouds)
         self.ws = _ws(self.nbytes, s_xyz.device)
         check(L.regtr_cellgrid_build(ptr(s_xyz), iptr(s_seg_off), self.n_clouds, self.ns_cap, self.radius, bptr(self.ws),
@@ -47,9 +50,13 @@ class CellGrid:
         if want_count:
             cnt = torch.empty(max(nq_cap, 1), dtype=torch.int32, device=q_xyz.device)
             mx = torch.zeros(1, dtype=torch.int32, device=q_xyz.device)
-        check(L.regtr_radius_query(ptr(q_xyz), iptr(q_seg_off), int(nq_cap), iptr(self.s_seg_off), self.ns_cap,
-                                   self.n_clouds, self.radius, int(K), bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt),
-                                   iptr(mx), stream()), 'regtr_radius_query')
+        if self_query_kernel and q_xyz is self.s_xyz and q_seg_off is self.s_seg_off:     # the grid's own supports: cell-centric kernel
+            check(L.regtr_radius_query_self(iptr(self.s_seg_off), self.ns_cap, self.n_clouds, self.radius, int(K), bptr(self.ws),
+                                            self.nbytes, iptr(idx), iptr(cnt), iptr(mx), stream()), 'regtr_radius_query_self')
+        else:
+            check(L.regtr_radius_query(ptr(q_xyz), iptr(q_seg_off), int(nq_cap), iptr(self.s_seg_off), self.ns_cap,
+                                       self.n_clouds, self.radius, int(K), bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt),
+                                       iptr(mx), stream()), 'regtr_radius_query')
         return (idx, cnt, mx) if want_count else idx
 
 

@@ -161,6 +161,12 @@ def _check_radius(q, ql, s, sl, r, K):
     assert np.array_equal(cnt[:len(q)].cpu().numpy(), ref_cnt)
     assert int(mx.item()) == (ref_cnt.max() if len(q) else 0)
     assert np.array_equal(idx[:len(q)].cpu().numpy(), ref_idx), 'neighbour indices not bit exact'
+    if q is s and len(q):
+        # queries == supports (the conv tables): the cell-centric self-query kernel must give the very same table
+        s_dev, s_seg = grid.s_xyz, grid.s_seg_off
+        idx2, cnt2, mx2 = grid.query(s_dev, s_seg, len(s), K, want_count=True)
+        assert np.array_equal(idx2[:len(q)].cpu().numpy(), ref_idx), 'self-query kernel: neighbour indices not bit exact'
+        assert np.array_equal(cnt2[:len(q)].cpu().numpy(), ref_cnt) and int(mx2.item()) == ref_cnt.max()
     return idx[:len(q)]
 
 
