@@ -44,6 +44,18 @@ def _seg(lens):
     return torch.tensor(np.concatenate([[0], np.cumsum(lens)]).astype(np.int32), device=_dev()), lens
 
 
+def _canonical_rows(idx, q, s):
+    """Rows of a neighbour table re-ordered to ascending (d2, index), d2 in the reference's float32 arithmetic
+    ((0 + dx*dx) + dy*dy) + dz*dz (nanoflann.hpp:432-440; separate torch kernels, so nothing is contracted into an FMA)."""
+    pad = s.shape[0]
+    sp = torch.cat([s, torch.zeros((1, 3), dtype=s.dtype, device=s.device)])
+    d = q[:, None, :] - sp[idx.long()]
+    d2 = ((d[..., 0] * d[..., 0]) + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    key = (d2.view(torch.int32).long() << 32) | idx.long()
+    key[idx == pad] = torch.iinfo(torch.int64).max
+    return torch.gather(idx, 1, torch.argsort(key, dim=1, stable=True))
+
+
 class _Subsampling:
     @staticmethod
     def subsample_batch(points, batches, features=None, classes=None, sampleDl=0.1, method='barycenters', max_p=0,
@@ -99,7 +111,12 @@ class _Neighbors:
                         break
                     K = min(448, max(2 * K, width))
                 if width > K:
-                    raise RuntimeError(f'batch_query: a ball holds {width} supports, above the kernel limit of 448')
+                    # more supports in one ball than the wavefront kernel's LDS list holds (448): the KD-tree kernel has no
+                    # limit; its rows (reference order) are re-sorted to the canonical (d2, index) order.  Rare (the
+                    # reference itself has no limit, neighbors.cpp:290-293) and off the model's hot path.
+                    tree = ops.KdTree(s, sseg, s.shape[0])
+                    idx, _ = tree.query(q, qseg, q.shape[0], float(radius), width, list_cap=width)
+                    idx = _canonical_rows(idx[:q.shape[0]], q, s)
         if width == 0:
             raise RuntimeError('Error converting output: no neighbour found')           # wrapper.cpp:201-205
         idx = idx[:q.shape[0], :width].contiguous()

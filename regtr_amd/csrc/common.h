@@ -18,6 +18,7 @@
 
 static inline size_t rg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int rg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int rg_xcd_grid(int nblocks) { return (nblocks + 7) / 8 * 8; }
 static inline unsigned rg_next_pow2(unsigned x)
 {
     unsigned p = 1;
@@ -43,6 +44,12 @@ struct RgCarver {
 };
 
 __device__ __forceinline__ int rg_lane() { return threadIdx.x & (RG_WAVE - 1); }
+
+// Workgroup b of a launch runs on XCD b % 8, and every XCD has its own L2.  Kernels whose neighbouring work items touch
+// overlapping memory (queries gathering the rows of their spatial neighbours) want neighbouring items on ONE L2: launch a
+// grid padded to a multiple of 8 (rg_xcd_grid) and take work block rg_xcd_block(blockIdx.x, gridDim.x) -- every XCD then owns
+// one contiguous eighth of the blocks instead of every eighth block.
+__device__ __forceinline__ int rg_xcd_block(int b, int grid_padded) { return (b & 7) * (grid_padded >> 3) + (b >> 3); }
 
 // index of the segment containing row i, given exclusive offsets off[0..nseg] (off[0] = 0)
 __device__ __forceinline__ int rg_find_segment(const int* __restrict__ off, int nseg, int i)

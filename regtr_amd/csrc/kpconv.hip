@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather(Gather
     float* flg_s = (float*)(idx_s + QW * H);
     float* xs_s = flg_s + QW * H;
 
-    const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
+    const int q0 = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * QW;      // XCD-contiguous query ranges
     if (q0 >= g.nq) return;   // wave-uniform
 
     // ---- phase 1: neighbour indices, centred offsets, positivity flags
@@ -232,13 +232,28 @@ template <> __device__ __forceinline__ float4 rg_buf_load<4>(__amdgpu_buffer_rsr
     const rg_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// Cache policy of the WF stores: nt (non-temporal, aux bit 1).  WF is written once, read once by the next kernel and is far
+// larger than every cache (4.6 GB at level 0 of a 64-pair forward): as default-policy stores it evicted the feature rows the
+// gather re-reads ~40 times from L2.  Measured on MI355X (tools/gather_bench.py, 64 pairs): all gather launches of a forward
+// 5.40 -> 4.94 ms (Cin 64: 950 -> 786 us, Cin 128: 438 -> 358 us); without any store they take 4.42 ms.
+#ifndef RG_WF_STORE_AUX
+#define RG_WF_STORE_AUX 2
+#endif
 __device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, const float2& v)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(rg_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, off, 0, 0);
+#ifndef RG_WF_SKIP_STORE
+    __builtin_amdgcn_raw_buffer_store_b64(rg_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, off, 0, RG_WF_STORE_AUX);
+#else
+    if (v.x == 1.2345e30f) __builtin_amdgcn_raw_buffer_store_b64(rg_u32x2{__float_as_uint(v.x), __float_as_uint(v.y)}, r, off, 0, 0);
+#endif
 }
 __device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned off, const float4& v)
 {
-    __builtin_amdgcn_raw_buffer_store_b128(rg_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+#ifndef RG_WF_SKIP_STORE
+    __builtin_amdgcn_raw_buffer_store_b128(rg_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, RG_WF_STORE_AUX);
+#else
+    if (v.x == 1.2345e30f) __builtin_amdgcn_raw_buffer_store_b128(rg_u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, r, off, 0, 0);
+#endif
 }
 
 #ifndef RG_MG_WAVES_PER_EU
@@ -273,7 +288,8 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     // All gathers are BRANCH FREE (range-checked buffer loads, clamped rows): predicated loads would split the code into
     // basic blocks, and hipcc drains every outstanding load (s_waitcnt vmcnt(0)) at block boundaries, serialising the
     // prefetch.
-    const int qbase = (blockIdx.x * GATHER_WAVES + wave) * MG_QPW;
+    // XCD-aware: each XCD (own L2) takes one contiguous eighth of the queries -- neighbouring queries gather the same rows
+    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * MG_QPW;
     if (qbase >= nq) return;
     const int hl = lane < H ? lane : H - 1;
     auto load_idx = [&](int q) -> int {
@@ -415,7 +431,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
     float* rel_s = smem + (size_t)wave * QW * H * 5;      // rel[QW][H][3] | x[QW][H] | flag[QW][H]
     float* xs_s = rel_s + QW * H * 3;
     float* flg_s = xs_s + QW * H;
-    const int q0 = (blockIdx.x * GATHER_WAVES + wave) * QW;
+    const int q0 = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * QW;
     if (q0 >= g.nq) return;
     for (int e = lane; e < QW * H; e += RG_WAVE) {
         const int qi = e / H, h = e - qi * H, q = q0 + qi;
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
 {
     constexpr int LQ = RG_WAVE / QW;                 // lanes per query
     const int lane = rg_lane();
-    const int q = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * QW + lane / LQ;
+    const int q = (rg_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * QW + lane / LQ;      // XCD-contiguous
     if (q >= nq) return;
     const int* row = nbr + (size_t)q * ld_nbr;
     for (int c = (lane % LQ) * 4; c < C; c += LQ * 4) {
@@ -519,14 +535,14 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     if (Cin == 1) {
         if (x_stats) return RG_ERR_ARG;
         const size_t lds1 = (size_t)GATHER_WAVES * 4 * H * 5 * sizeof(float);
-        k_kpconv_gather_c1<<<rg_cdiv(nq, GATHER_WAVES * 4), GATHER_WAVES * RG_WAVE, lds1, st>>>(g);
+        k_kpconv_gather_c1<<<rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * 4)), GATHER_WAVES * RG_WAVE, lds1, st>>>(g);
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }
     const bool aligned16 = (((uintptr_t)x | (uintptr_t)wf | (uintptr_t)x_stats) & 15) == 0;
     if (!flag && !(aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29))) return RG_ERR_ARG;
     if (regtr_kpconv_gather_computes_flag(Cin, H) && aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29)) {   // matrix-core path
-        const int grid_m = rg_cdiv(nq, GATHER_WAVES * MG_QPW);
+        const int grid_m = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * MG_QPW));
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
         const bool v4 = Cin % 64 == 0;
 #define RG_LAUNCH_MG(JJ) do { if (v4) k_kpconv_gather_mfma<JJ, 4><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); \
@@ -540,7 +556,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     const int QW = RG_WAVE / LQ;
     const size_t lds = (size_t)GATHER_WAVES * ((QW * H * (KP_PAD + 6) + 3) & ~3) * sizeof(float);
     if (lds > 160 * 1024) return RG_ERR_ARG;
-    const int grid = rg_cdiv(nq, GATHER_WAVES * QW);
+    const int grid = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * QW));
     if (LQ == 16) k_kpconv_gather<16><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else if (LQ == 32) k_kpconv_gather<32><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else k_kpconv_gather<64><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
@@ -552,9 +568,9 @@ int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_n
 {
     if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || ld_nbr < H || C < 4 || C % 4) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
-    if (C <= 64) k_maxpool_gather<4><<<rg_cdiv(nq, 16), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
-    else if (C <= 128) k_maxpool_gather<2><<<rg_cdiv(nq, 8), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
-    else k_maxpool_gather<1><<<rg_cdiv(nq, 4), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+    if (C <= 64) k_maxpool_gather<4><<<rg_xcd_grid(rg_cdiv(nq, 16)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+    else if (C <= 128) k_maxpool_gather<2><<<rg_xcd_grid(rg_cdiv(nq, 8)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+    else k_maxpool_gather<1><<<rg_xcd_grid(rg_cdiv(nq, 4)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

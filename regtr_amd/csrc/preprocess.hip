@@ -520,7 +520,12 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
     const unsigned mask = rg_live_table(ns) - 1u;      // the table was built for ns supports
     // Grid-stride over the LIVE queries: the launch is sized for the level-0 capacity (live counts exist only on the
     // device), and a level with 1/64 of the rows must not pay for 63/64 empty workgroups.
-    for (int q = blockIdx.x * QUERY_WAVES + wave; q < nq; q += gridDim.x * QUERY_WAVES) {   // wave-uniform
+    // (every wave takes a CONTIGUOUS run of queries, and every XCD -- own L2 -- a contiguous eighth of them: neighbouring queries
+    //  read the same cell runs)
+    const int per_wave = (nq + gridDim.x * QUERY_WAVES - 1) / (gridDim.x * QUERY_WAVES);
+    const int q_first = (rg_xcd_block(blockIdx.x, gridDim.x) * QUERY_WAVES + wave) * per_wave;
+    const int q_last = min(nq, q_first + per_wave);
+    for (int q = q_first; q < q_last; q++) {   // wave-uniform
     const int cid = rg_find_segment_wave(q_seg_off, n_clouds, q);    // q is wave-uniform: one round trip, not log2(n) dependent loads
     const float qx = q_xyz[3 * (size_t)q], qy = q_xyz[3 * (size_t)q + 1], qz = q_xyz[3 * (size_t)q + 2];
     const float r2 = __fmul_rn(radius, radius);  // neighbors.cpp:226
@@ -943,7 +948,7 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     if (cap > 512) cap = 512;          // 8 register-staged chunks of 64 in the shrink path
     if (cap < K + RG_WAVE) return RG_ERR_ARG;   // K <= 448
     const size_t lds = (size_t)QUERY_WAVES * (cap + 32) * sizeof(uint64_t);
-    const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_cdiv(nq_cap, QUERY_WAVES) : 256 * 64;   // grid-stride inside
+    const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_xcd_grid(rg_cdiv(nq_cap, QUERY_WAVES)) : 256 * 64;   // query runs inside
     k_radius_query<<<grid, QUERY_WAVES * RG_WAVE, lds, st>>>(
         q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, out_idx, out_count, out_max_count);
     RG_RETURN_IF_LAUNCH_FAILED();

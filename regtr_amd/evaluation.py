@@ -89,6 +89,10 @@ def rotation_error_deg(R_gt, R_est):
 def benchmark(est_folder, gt_folder):
     """(:285-374) -> (table string, mean recall over scenes).  est_folder/<scene>/est.log vs gt_folder/<scene>/gt.{log,info}."""
     scenes = sorted(os.listdir(gt_folder))
+    missing = [sc for sc in scenes if not os.path.exists(os.path.join(est_folder, sc, 'est.log'))]
+    if missing:       # a partial run (--max_pairs, an interrupted job): the reference would die on the first missing file (:301)
+        raise RuntimeError(f'benchmark: no est.log for scene(s) {missing} under {est_folder}; the registration recall is defined '
+                           'over the complete test set -- run every pair (no --max_pairs) before evaluating')
     out = 'Scene\t¦ prec.\t¦ rec.\t¦ re\t¦ te\t¦ samples\t¦\n'
     precision, recall, n_valids, med_re, med_te = [], [], [], [], []
     for idx, scene in enumerate(scenes):

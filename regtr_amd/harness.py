@@ -163,9 +163,11 @@ class Prefetcher:
 
 
 # ------------------------------------------------------------------------------------------------------ result files
-def write_est_log(log_path, benchmark, records):
+def write_est_log(log_path, benchmark, records, append=False):
     """generic_reg_model.py:260-281: per scene `<log_path>/<benchmark>/<scene>/est.log`, one block per pair:
-    "{tgt_idx}\\t{src_idx}\\t-1" then the 4x4 pose, rows tab-separated with 12 decimals."""
+    "{tgt_idx}\\t{src_idx}\\t-1" then the 4x4 pose, rows tab-separated with 12 decimals.
+    A run writes each scene's file once, so the file is TRUNCATED unless append=True -- the reference opens it in append
+    mode per pair (:276), which duplicates blocks (and corrupts the recall) when a run is repeated into the same log folder."""
     by_scene = {}
     for rec in records:
         scene = rec['src_path'].split(os.path.sep)[1]
@@ -173,7 +175,7 @@ def write_est_log(log_path, benchmark, records):
     for scene, recs in by_scene.items():
         folder = os.path.join(log_path, benchmark, scene)
         os.makedirs(folder, exist_ok=True)
-        with open(os.path.join(folder, 'est.log'), 'a') as fid:
+        with open(os.path.join(folder, 'est.log'), 'a' if append else 'w') as fid:
             for rec in recs:
                 src_idx = int(os.path.basename(rec['src_path']).split('_')[-1].replace('.pth', ''))
                 tgt_idx = int(os.path.basename(rec['tgt_path']).split('_')[-1].replace('.pth', ''))

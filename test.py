@@ -112,7 +112,8 @@ def main():
         pairs = harness.SyntheticPairs(opt.synthetic, points=20000 if cfg.dataset == '3dmatch' else 717)
     elif cfg.dataset == '3dmatch':
         info = opt.info or os.path.join('datasets', '3dmatch', f'test_{opt.benchmark}_info.pkl')
-        roots = [opt.data_root] if opt.data_root else ([cfg.root] if isinstance(cfg.root, str) else list(cfg.root))
+        cfg_root = cfg.get('root', None)         # the shipped regtr_amd/conf/*.yaml carry no dataset root: --data_root supplies it
+        roots = [opt.data_root] if opt.data_root else ([cfg_root] if isinstance(cfg_root, str) else list(cfg_root or []))
         root = next((r for r in roots if os.path.exists(os.path.join(r, 'test'))), None)
         if root is None or not os.path.exists(info):
             logger.error(f'Dataset not found (info {info}, roots {roots}); pass --data_root / --info or use --synthetic N')
@@ -142,7 +143,10 @@ def main():
             harness.write_est_log(opt.log_path, opt.benchmark, recs)
             logger.info(f'est.log files written under {os.path.join(opt.log_path, opt.benchmark)}')
             gt_folder = os.path.join(opt.benchmark_dir, opt.benchmark)
-            if opt.synthetic == 0 and os.path.isdir(gt_folder):
+            complete = opt.max_pairs is None or opt.max_pairs <= 0 or opt.max_pairs >= len(pairs)
+            if opt.synthetic == 0 and os.path.isdir(gt_folder) and not complete:
+                logger.warning('partial run (--max_pairs): the registration recall needs every pair of the benchmark; skipping the evaluation')
+            if opt.synthetic == 0 and os.path.isdir(gt_folder) and complete:
                 # Evaluate 3DMatch registration recall (generic_reg_model.py:180-186), in process
                 from regtr_amd.evaluation import benchmark
                 results_str, mean_recall = benchmark(os.path.join(opt.log_path, opt.benchmark), gt_folder)

@@ -265,6 +265,21 @@ def test_cpp_wrappers_dropin():
         radius_neighbors.batch_query(pts[:, :2], pts, lens, lens, radius=0.1)
 
 
+def test_cpp_wrappers_more_than_448_supports_in_a_ball():
+    """batch_query has no row-width limit in the reference (neighbors.cpp:290-293); above the wavefront kernel's 448 the drop-in
+    answers through the KD-tree kernel and re-sorts to the canonical order."""
+    from oracle import native
+    from regtr_amd.cpp_wrappers import radius_neighbors
+    rng = np.random.default_rng(4)
+    dense = rng.uniform(0, 0.05, (700, 3)).astype(np.float32)
+    far = (rng.uniform(0, 1, (300, 3)) + 3).astype(np.float32)
+    pts = np.concatenate([dense, far]); lens = np.array([1000], np.int32)
+    nb = radius_neighbors.batch_query(pts, pts, lens, lens, radius=0.2)
+    assert nb.shape[1] > 448
+    ref, _, _ = native.radius_neighbors(pts, pts, lens, lens, 0.2, nb.shape[1])
+    assert np.array_equal(nb, ref)
+
+
 @pytest.mark.parametrize('case', ['modelnet', '3dmatch_crop'])
 def test_cpp_wrappers_reference_order(case):
     """cpp_wrappers.reference_order(True): both drop-in ops return what the unmodified reference C++ returned (committed

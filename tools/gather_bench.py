@@ -42,8 +42,8 @@ def main():
         wf = torch.empty(nq, 15 * Cin, device=dev); num = torch.empty(nq, device=dev)
 
         def run():
-            _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.ptr(nbr), H, _lib.ptr(x), Cin, None,
-                                             _lib.ptr(kp), 15, radius * 0.8, _lib.ptr(st), _lib.ptr(seg_q), seg_q.numel() - 1, 0.1,
+            _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.iptr(nbr), H, _lib.ptr(x), Cin, None,
+                                             _lib.ptr(kp), 15, radius * 0.8, _lib.ptr(st), _lib.iptr(seg_q), seg_q.numel() - 1, 0.1,
                                              _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
         for _ in range(3):
             run()
