@@ -112,9 +112,16 @@ class on_device:
 
 def ptr(t, dtype=torch.float32):
     """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous, of the dtype the kernel reads (float32
-    unless stated) and live on the GPU the launch goes to."""
+    unless stated) and live on the GPU the launch goes to.  (Called a few thousand times per forward: three C-level calls.)"""
     if t is None:
         return None
+    dev = _active_device[0]
+    if t.get_device() != (dev if dev is not None else torch.cuda.current_device()) or t.dtype is not dtype or not t.is_contiguous():
+        _explain(t, dtype)
+    return t.data_ptr()
+
+
+def _explain(t, dtype):
     if not t.is_cuda:
         raise RuntimeError('regtr_amd ops need GPU tensors (no CPU fallback)')
     if t.dtype != dtype:
@@ -122,10 +129,8 @@ def ptr(t, dtype=torch.float32):
     if not t.is_contiguous():
         raise RuntimeError('regtr_amd ops need contiguous tensors')
     dev = _active_device[0]
-    if t.device.index != (dev if dev is not None else torch.cuda.current_device()):
-        raise RuntimeError(f'tensor on {t.device} but the launch device is cuda:{dev if dev is not None else torch.cuda.current_device()}; '
-                           'wrap the call in regtr_amd._lib.on_device(tensor.device)')
-    return t.data_ptr()
+    raise RuntimeError(f'tensor on {t.device} but the launch device is cuda:{dev if dev is not None else torch.cuda.current_device()}; '
+                       'wrap the call in regtr_amd._lib.on_device(tensor.device)')
 
 
 def iptr(t):
@@ -144,7 +149,7 @@ def raw(t):
     """data_ptr of a float32 row-strided view (unit column stride is the caller's business)."""
     if t is None:
         return None
-    if not t.is_cuda or t.dtype != torch.float32:
+    if t.dtype is not torch.float32 or t.get_device() < 0:
         raise RuntimeError(f'regtr_amd op expected a float32 GPU tensor, got {t.dtype} on {t.device}')
     return t.data_ptr()
 

@@ -465,7 +465,11 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
     if (max_len == 0) return RG_OK;
     MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
     hipStream_t st = (hipStream_t)stream;
-    if (precision == 2) k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, st>>>(g);
+    // Small problems (a pair or two per forward: fewer than two 4-wave workgroups per CU): the single-wave exact-f32 kernel puts
+    // four times as many workgroups on the chip and stages K / V without the split -- 32 us against 56 us per launch at one
+    // 3DMatch pair.  Both are float32-grade, so precision 0 may take either.
+    const bool small = (long long)rg_cdiv(max_len, BW * TQ) * n_heads * n_clouds < 512;
+    if (precision == 2 || (precision == 0 && small)) k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, st>>>(g);
     else {
         if ((ldv % 2) || ((uintptr_t)v % 8)) return RG_ERR_ARG;
         const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);

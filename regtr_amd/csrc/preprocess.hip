@@ -637,11 +637,18 @@ k_radius_query_self(const int* __restrict__ s_seg_off, int n_clouds, GridView g,
     const unsigned T = rg_live_table(ns), mask = T - 1u;
     const float r2 = __fmul_rn(radius, radius);  // neighbors.cpp:226
     int wave_max = 0;
-    // grid-stride over chunks of 64 hash slots; the occupied ones of a chunk are handled one after another
-    for (unsigned h0 = (blockIdx.x * QUERY_WAVES + wave) * RG_WAVE; h0 < T; h0 += gridDim.x * QUERY_WAVES * RG_WAVE) {
-        const CellSlot* sl = &g.slots[h0 + lane];
-        const uint4 sa = *(const uint4*)sl;                                  // key | cid | used
+    // The live table's T slots are dealt to the launched waves in chunks of `spw` consecutive slots (a power of two, 4..64, sized
+    // on the device so that every wave gets work: a small cloud set must not leave most of the chip idle while a few waves walk
+    // 64 slots -- ~6 cells x ~6 queries -- one after another); the occupied slots of a chunk are handled one after another.
+    const unsigned n_waves = gridDim.x * QUERY_WAVES;
+    unsigned spw = 4;
+    while (spw < 64u && spw * n_waves < T) spw <<= 1;
+    for (unsigned h0 = (blockIdx.x * QUERY_WAVES + wave) * spw; h0 < T; h0 += n_waves * spw) {
+        const bool mine = (unsigned)lane < spw;
+        const CellSlot* sl = &g.slots[h0 + (mine ? lane : 0)];
+        uint4 sa = *(const uint4*)sl;                                        // key | cid | used
         const uint2 sb = *(const uint2*)((const char*)sl + 16);               // cnt | start
+        if (!mine) sa.w = 0xffffffffu;                                        // lanes beyond the chunk: "unused"
         unsigned long long occ = __ballot((int)sa.w >= 0 && (int)sb.x > 0);
         while (occ) {
             const int src = __ffsll((long long)occ) - 1;
@@ -970,8 +977,8 @@ int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, floa
     if (cap > 512) cap = 512;
     if (cap < K + RG_WAVE) return RG_ERR_ARG;
     const size_t lds = (size_t)QUERY_WAVES * (SELF_CAND * 16 + (size_t)cap * 8 + 256);
-    // one wave per 64 hash slots of the LIVE table (<= 3 x ns_cap slots); grid-stride inside
-    const long long chunks = ((long long)b.T + RG_WAVE - 1) / RG_WAVE;
+    // waves for 16 slots each of the table's capacity, at most 32 workgroups per CU; the kernel sizes the chunks for the live table
+    const long long chunks = ((long long)b.T + 15) / 16;
     const int grid = (int)(rg_cdiv(chunks, QUERY_WAVES) < 256 * 32 ? rg_cdiv(chunks, QUERY_WAVES) : 256 * 32);
     k_radius_query_self<<<grid, QUERY_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(s_seg_off, n_clouds, g, radius, K, cap, out_idx,
                                                                                      out_count, out_max_count);

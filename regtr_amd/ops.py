@@ -29,6 +29,7 @@ def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0):
 
 
 self_query_kernel = True     # tests / A-B runs: False routes self queries through the per-query kernel as well
+SELF_QUERY_MIN_POINTS = 262144      # measured: 38k points (one pair) 48 us vs 15 us per table; 2.4M points (64 pairs) 1.25 vs 1.9 ms
 
 
 class CellGrid:
@@ -50,7 +51,8 @@ class CellGrid:
         if want_count:
             cnt = torch.empty(max(nq_cap, 1), dtype=torch.int32, device=q_xyz.device)
             mx = torch.zeros(1, dtype=torch.int32, device=q_xyz.device)
-        if self_query_kernel and q_xyz is self.s_xyz and q_seg_off is self.s_seg_off:     # the grid's own supports: cell-centric kernel
+        # the grid's own supports: cell-centric kernel (large sets only: one wave per query keeps more of the chip busy on a pair or two)
+        if self_query_kernel and q_xyz is self.s_xyz and q_seg_off is self.s_seg_off and self.ns_cap >= SELF_QUERY_MIN_POINTS:
             check(L.regtr_radius_query_self(iptr(self.s_seg_off), self.ns_cap, self.n_clouds, self.radius, int(K), bptr(self.ws),
                                             self.nbytes, iptr(idx), iptr(cnt), iptr(mx), stream()), 'regtr_radius_query_self')
         else:

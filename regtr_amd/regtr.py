@@ -132,6 +132,15 @@ class RegTR(nn.Module):
             self.feature_criterion_un = _LossParams(cfg.d_embed)
         self._cache = {}
         self.last_timings = None
+        self._params_checked = False
+
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .half() / .double(): re-validate at the next forward
+        self._params_checked = False
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._params_checked = False
+        return super().load_state_dict(*args, **kwargs)
 
     @property
     def device(self):
@@ -143,11 +152,14 @@ class RegTR(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError('regtr_amd.RegTR runs on an MI355X (HIP) device only; there is no CPU path')
         clouds = batch['src_xyz'] + batch['tgt_xyz']
-        if any(p.device != dev for p in clouds) or self.device != dev:
-            raise RuntimeError(f'RegTR.forward: the model ({self.device}) and every input cloud must live on one GPU ({dev})')
-        bad = [n for n, p in self.named_parameters() if p.dtype != torch.float32]
-        if bad:
-            raise RuntimeError(f'regtr_amd.RegTR computes in float32; non-float32 parameters: {bad[:3]} ...')
+        if not self._params_checked:        # once per parameter (re)placement: _apply() below resets it
+            bad = [n for n, p in self.named_parameters() if p.dtype != torch.float32]
+            if bad:
+                raise RuntimeError(f'regtr_amd.RegTR computes in float32; non-float32 parameters: {bad[:3]} ...')
+            self._model_device = next(self.parameters()).device
+            self._params_checked = True
+        if any(p.device != dev for p in clouds) or self._model_device != dev:
+            raise RuntimeError(f'RegTR.forward: the model ({self._model_device}) and every input cloud must live on one GPU ({dev})')
         # kernels go to torch's current stream of the CURRENT device: make the tensors' device current for the whole forward
         with _lib.on_device(dev):
             return self._forward(batch, dev)

@@ -164,7 +164,11 @@ def _check_radius(q, ql, s, sl, r, K):
     if q is s and len(q):
         # queries == supports (the conv tables): the cell-centric self-query kernel must give the very same table
         s_dev, s_seg = grid.s_xyz, grid.s_seg_off
-        idx2, cnt2, mx2 = grid.query(s_dev, s_seg, len(s), K, want_count=True)
+        ops.SELF_QUERY_MIN_POINTS, keep = 0, ops.SELF_QUERY_MIN_POINTS
+        try:
+            idx2, cnt2, mx2 = grid.query(s_dev, s_seg, len(s), K, want_count=True)
+        finally:
+            ops.SELF_QUERY_MIN_POINTS = keep
         assert np.array_equal(idx2[:len(q)].cpu().numpy(), ref_idx), 'self-query kernel: neighbour indices not bit exact'
         assert np.array_equal(cnt2[:len(q)].cpu().numpy(), ref_cnt) and int(mx2.item()) == ref_cnt.max()
     return idx[:len(q)]
@@ -395,7 +399,8 @@ def test_layernorm_posemb_vs_oracle():
 
 
 @pytest.mark.parametrize('precision,tol', [(0, 2e-5), (2, 2e-5), (1, 6e-2)])
-@pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900], [130, 0, 5, 129]])
+@pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900], [130, 0, 5, 129],
+                                  [150, 97, 260, 33] * 10 + [170, 0, 129, 64] * 10])      # the last one: enough workgroups for the 4-wave kernel
 def test_mha_vs_oracle(lens, precision, tol):
     """self- and cross-attention cores on packed ragged clouds vs the plain softmax(QK^T)V restatement in float64:
     precision 0 (bf16x3 split MFMA, the default) and 2 (exact-f32 MFMA) at float32 accuracy, 1 (plain bf16 operands) at

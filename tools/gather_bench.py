@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--pairs', type=int, default=16)
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--no-fold', action='store_true', help='features already normalised: no InstanceNorm+LeakyReLU fold in the gather')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     cfg = load_config(os.path.join(bench.ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
@@ -43,7 +44,7 @@ def main():
 
         def run():
             _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.iptr(nbr), H, _lib.ptr(x), Cin, None,
-                                             _lib.ptr(kp), 15, radius * 0.8, _lib.ptr(st), _lib.iptr(seg_q), seg_q.numel() - 1, 0.1,
+                                             _lib.ptr(kp), 15, radius * 0.8, None if args.no_fold else _lib.ptr(st), None if args.no_fold else _lib.iptr(seg_q), 0 if args.no_fold else seg_q.numel() - 1, 0.1,
                                              _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
         for _ in range(3):
             run()

@@ -17,5 +17,6 @@ for grp in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAV
   timeout 600 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $out/pmc_$i -o p -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $out/pmc_$i.log 2>&1 || tail -3 $out/pmc_$i.log
 done
 python tools/pmc_summary.py --traffic $out k_kpconv_gather > $out/pmc_traffic.json 2>&1; tail -12 $out/pmc_traffic.json
+python tools/pmc_summary.py --bench-traffic $out $tag > $out/pmc_traffic_bench.json 2>&1
 python tools/pmc_summary.py --mfma $out > $out/pmc_mfma.md 2>&1; cat $out/pmc_mfma.md
 find $out -name "*.csv" -size +4M -delete

@@ -62,6 +62,24 @@ def traffic_json(out, kernel_sub, calib_sub='k_instnorm_partial'):
     print(json.dumps(res, indent=1))
 
 
+def bench_traffic_json(out, tag, pairs=64, points=20000, shuffle=False):
+    """profiles/pmc_traffic.json for bench.py's `roofline.traffic`: mean HBM bytes per KPConv-gather launch of the PMC passes under
+    `out` (taken over `python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline` on the default workload)."""
+    import io, json, contextlib
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        traffic_json(out, 'k_kpconv_gather')
+    kernels = json.loads(buf.getvalue())
+    g = {k: v for k, v in kernels.items() if 'k_kpconv_gather' in k}
+    n = sum(v['launches'] for v in g.values())
+    total = sum(v['fetch_bytes_total'] + v['write_bytes_total'] for v in g.values())
+    print(json.dumps({'workload': {'pairs': pairs, 'points': points, 'shuffle': shuffle}, 'hbm_bytes_per_launch': total / max(n, 1),
+                      'source': f'profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) over '
+                                '`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline`; bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B '
+                                f'requests at 64 B) + WRITE_SIZE KB; mean over the {n} gather launches of {n // 11} forwards',
+                      'kernels': kernels}, indent=1))
+
+
 def mfma_table(out):
     """Matrix-core utilisation per kernel: SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), kernel cycles =
     GRBM_GUI_ACTIVE / 8 (the counter is summed over the 8 XCDs); plus the wave-cycle split (SQ_* are quad-cycles)."""
@@ -88,6 +106,8 @@ def mfma_table(out):
 if __name__ == '__main__':
     if len(sys.argv) > 2 and sys.argv[1] == '--mfma':
         mfma_table(sys.argv[2])
+    elif len(sys.argv) > 3 and sys.argv[1] == '--bench-traffic':
+        bench_traffic_json(sys.argv[2], sys.argv[3])
     elif len(sys.argv) > 2 and sys.argv[1] == '--traffic':
         traffic_json(*sys.argv[2:4])
     else:
