@@ -125,8 +125,13 @@ def test_stress_100k_full_tables_and_forward_vs_oracle():
     model.load_state_dict(sd)
     model = model.cuda().eval()
     batch = {'src_xyz': [torch.from_numpy(src).cuda()], 'tgt_xyz': [torch.from_numpy(tgt).cuda()]}
-    out = model(batch)
-    torch.cuda.synchronize()
+    from regtr_amd import ops
+    ops.SELF_QUERY_MIN_POINTS, keep = 0, ops.SELF_QUERY_MIN_POINTS        # conv tables through the cell-centric kernel (as in large batches)
+    try:
+        out = model(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.SELF_QUERY_MIN_POINTS = keep
     meta = batch['kpconv_meta']
     rmeta = _ref_canonical_meta([src, tgt], cfg)
     for l in range(len(rmeta['points'])):
