@@ -1,5 +1,7 @@
 """Tensor-level wrappers over the C ABI (include/regtr_hip.h).  torch is used for device memory and the current
-stream only; every arithmetic step runs in libregtr_hip.so.  Nothing here synchronises with the host."""
+stream only; every arithmetic step runs in libregtr_hip.so.  Nothing here synchronises with the host, with one documented
+exception: `KdTree` (the reference-order parity mode) reads its row width back.  Every pointer handed to the library is checked
+for device, dtype and contiguity (_lib.ptr / iptr / bptr / dptr)."""
 import math
 
 import torch
