@@ -23,7 +23,7 @@ def _worker(rank, world, port, n_pairs, q):
     poses = torch.stack([torch.arange(12, dtype=torch.float32) + 100.0 * i for i in mine]) if mine else torch.zeros(0, 12)
     ids = torch.tensor(mine, dtype=torch.int32)
     all_poses, all_ids = gather_poses(poses, ids)
-    q.put((rank, all_poses.clone(), all_ids.clone()))
+    q.put((rank, all_poses.numpy().copy(), all_ids.numpy().copy()))      # by value: torch tensors travel as fds that die with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -42,7 +42,7 @@ def test_pose_gather_world2(n_pairs):
     exp = torch.stack([torch.arange(12, dtype=torch.float32) + 100.0 * i for i in range(n_pairs)])
     for _, poses, ids in results:
         assert ids.tolist() == list(range(n_pairs))
-        assert torch.equal(poses, exp)
+        assert torch.equal(torch.from_numpy(poses), exp)
 
 
 def test_shard_pairs_partition():
