@@ -174,10 +174,27 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, void* stream);
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, void* stream);
+/* tile_info (optional): regtr_tile_segments(seg_off, n_seg, M, regtr_gemm_x3_tile_rows(M,N,K), ..) -- 16 bytes per row tile that
+ * replace the per-workgroup cloud search (a chain of dependent memory round trips) when a_stats / stat_partial are used; a_seg_off
+ * and stat_seg_off must then be the same array. */
+int regtr_tile_segments(const int* seg_off, int n_seg, int M, int rows, void* out, void* stream);
+int regtr_gemm_x3_tile_rows(int M, int N, int K);
 /* n_planes: 3 = the float32-grade six-term product (default everywhere); 2 = three leading terms (a0 w0 + a0 w1 + a1 w0,
  * ~2^-16 relative per product); 1 = plain bf16 operands with float32 accumulation (cfg.compute_dtype 'bf16').  1 and 2 do not
  * combine with a_stats / stat_partial (the KPConv encoder always runs float32-grade). */
+/* One-shot strip variant for the shallow encoder levels (K in {32, 64, 128}, N <= 256, millions of rows; csrc/gemm_stream.hip):
+ * every wave takes 32 rows from global memory straight into MFMA fragments, the weight planes sit in LDS per 256-row workgroup,
+ * nothing is loaded after a store.  Same float32-grade product as regtr_gemm_x3:  C = A' W.
+ *   a_stats [n_seg,K,2] (K <= 64): A' = LeakyReLU_a_slope(InstanceNorm(A)); seg_off [n_seg+1]: cloud offsets of the rows;
+ *   tile_info = regtr_tile_segments(seg_off, n_seg, M, regtr_gemm_stream_tile_rows(), ..);
+ *   stat_partial (optional) = (ceil(M / 256) + n_seg) * N double2 of per-(tile, cloud) column sums of C for
+ *   regtr_instnorm_finalize_tiles(tile_rows = 256). */
+int regtr_gemm_stream_supported(int M, int N, int K);
+int regtr_gemm_stream_tile_rows(void);
+int regtr_gemm_stream(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
+                      const float* a_stats, float a_slope, const int* seg_off, int n_seg, const void* tile_info,
+                      double* stat_partial, void* stream);
 /* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
  * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud
  * offsets of C's rows; then regtr_instnorm_finalize_tiles(stat_partial, seg_off, n_clouds, N, R, eps, stats) yields the

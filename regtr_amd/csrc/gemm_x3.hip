@@ -49,6 +49,7 @@ struct X3Args {
     float* partial;
     double2* stat_partial;       // optional: per (row-tile, cloud) column sums / sums of squares of C  [slot][N]
     const int* stat_seg_off;     // cloud offsets of the rows of C (n_stat_seg + 1)
+    const int4* tile_info;       // optional: per row tile (first cloud, last cloud, first cloud's begin row, its end row)
     size_t plane;                // elements per weight plane = Npad * Kp
     int M, N, K, Kp, lda, ldc, ldr, act, n_seg, k_chunk, n_stat_seg;
     float a_slope;
@@ -116,6 +117,14 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     // bandwidth or MFMA, sets the time.
     int seg_first = 0, seg_last = 0, s_lo = 0, s_hi = 0, s_lo_begin = 0, s_lo_end = 0;
     const int row_last = min(m0 + BM, g.M) - 1;
+    if ((SOUT || STATS) && g.tile_info) {
+        // ONE 16-byte load instead of a chain of dependent round trips (boundary search, then the found cloud's offsets): on the
+        // short-K launches that chain, times the rounds of workgroups per CU, set the kernel's time.  The table is per level
+        // (regtr_tile_segments), shared by every launch over the level's rows.
+        const int4 ti = g.tile_info[tile_m];
+        s_lo = ti.x; s_hi = ti.y; s_lo_begin = ti.z; s_lo_end = ti.w;
+        seg_first = s_lo; seg_last = s_hi;
+    } else {
     if (SOUT) {
         s_lo = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, m0);
         s_hi = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, row_last);
@@ -127,6 +136,7 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
             seg_first = rg_find_segment_wave(g.a_seg_off, g.n_seg, m0);
             seg_last = rg_find_segment_wave(g.a_seg_off, g.n_seg, row_last);
         }
+    }
     }
 #pragma unroll
     for (int i = 0; i < AV; i++) {
@@ -360,6 +370,16 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
     Wt[e] = (uint16_t)(p0 & 0xffffu); Wt[plane + e] = (uint16_t)(p1 & 0xffffu); Wt[2 * plane + e] = (uint16_t)(p2 & 0xffffu);
 }
 
+// tile t of `rows` rows -> (first cloud, last cloud, first cloud's begin, first cloud's end); one thread per tile
+__global__ void __launch_bounds__(256) k_tile_segments(const int* __restrict__ seg_off, int n_seg, int M, int rows, int4* __restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((long long)t * rows >= M) return;
+    const int r0 = t * rows, r1 = min(M, r0 + rows) - 1;
+    const int lo = rg_find_segment(seg_off, n_seg, r0), hi = rg_find_segment(seg_off, n_seg, r1);
+    out[t] = make_int4(lo, hi, seg_off[lo], seg_off[lo + 1]);
+}
+
 struct X3Plan { int tile, splits, k_chunk; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64
 
 // tile shape and K split for a problem (host policy)
@@ -396,6 +416,26 @@ extern "C" {
 
 // 1 when regtr_gemm_x3 accepts the shape (otherwise use regtr_gemm_f32)
 int regtr_gemm_x3_supported(int M, int N, int K) { return (N >= 64 && N % 64 == 0 && K >= 16 && K % 4 == 0 && M >= 0) ? 1 : 0; }
+
+// Per row tile of `rows` rows (regtr_gemm_x3_stat_tile_rows / the launch's tile height): first and last cloud owning rows of the
+// tile and the first cloud's row range, 16 bytes per tile.  Built once per pyramid level and handed to every regtr_gemm_x3 launch
+// over that level's rows (tile_info), it replaces the boundary search + dependent offset loads at the head of every workgroup.
+// Empty clouds are skipped by the search (the containing cloud of a row is the last one starting at or before it).
+int regtr_tile_segments(const int* seg_off, int n_seg, int M, int rows, void* out, void* stream)
+{
+    if (!seg_off || !out || n_seg < 1 || M < 0 || rows < 1) return RG_ERR_ARG;
+    if (M == 0) return RG_OK;
+    k_tile_segments<<<rg_cdiv(rg_cdiv(M, rows), 256), 256, 0, (hipStream_t)stream>>>(seg_off, n_seg, M, rows, (int4*)out);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// tile height of the regtr_gemm_x3 launch for this shape (the `rows` of its tile_info)
+int regtr_gemm_x3_tile_rows(int M, int N, int K)
+{
+    if (!regtr_gemm_x3_supported(M, N, K)) return 0;
+    return x3_plan(M, N, K).tile == 2 ? 64 : 128;
+}
 
 // 1 when the split kernel is also the FASTER choice (measured on MI355X, tools/microbench.py): every supported shape with
 // at least one full k-tile; thinner contractions are pure streaming and stay on the exact-f32 kernel
@@ -444,9 +484,10 @@ int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, void* stream)
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, void* stream)
 {
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
+    if (tile_info && a_stats && stat_partial && (a_seg_off != stat_seg_off || n_seg != n_stat_seg)) return RG_ERR_ARG;
     if (n_planes < 1 || n_planes > 3 || (n_planes != 3 && (a_stats || stat_partial))) return RG_ERR_ARG;
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
@@ -456,7 +497,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
     X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
-             p.splits > 1 ? (float*)ws : nullptr, (double2*)stat_partial, stat_seg_off, (size_t)Npad * Kp,
+             p.splits > 1 ? (float*)ws : nullptr, (double2*)stat_partial, stat_seg_off, (const int4*)tile_info, (size_t)Npad * Kp,
              M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, n_stat_seg, a_slope};
     hipStream_t st = (hipStream_t)stream;
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;

@@ -3,6 +3,7 @@ stream only; every arithmetic step runs in libregtr_hip.so.  Nothing here synchr
 exception: `KdTree` (the reference-order parity mode) reads its row width back.  Every pointer handed to the library is checked
 for device, dtype and contiguity (_lib.ptr / iptr / bptr / dptr)."""
 import math
+import os
 
 import torch
 
@@ -115,7 +116,7 @@ class SplitWeight:
             self.K, self.N = w.shape
             self.kn = w
         self.planes = None
-        if L.regtr_gemm_x3_supported(1, self.N, self.K):
+        if L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
             check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
                                              stream()), 'regtr_gemm_split_weights')
@@ -135,6 +136,11 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     b_kn = sw.kn if sw is not None else b
     Kb, N = b_kn.shape
     assert K == Kb and a.stride(1) == 1 and b_kn.is_contiguous()
+    # the shallow encoder levels' Linears (short K, millions of rows, statistics wanted): one-shot strip kernel
+    if (sw is not None and sw.planes is not None and want_stats is not None and bias is None and row_div is None and residual is None
+            and not relu and planes == 3 and out is None and stream_ok(M, N, K, a, a_stats)
+            and (a_stats is None or a_seg_off is want_stats[0])):
+        return gemm_stream(a, sw, want_stats[0], a_stats=a_stats, a_slope=a_slope, want_stats=True, eps=eps)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldr = residual.stride(0) if residual is not None else 0
@@ -151,10 +157,14 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
             s_off = want_stats[0]
             n_clouds = s_off.numel() - 1
             partial = torch.empty((((M + R - 1) // R + n_clouds) * N, 2), dtype=torch.float64, device=a.device)
+        seg_rows = s_off if R else a_seg_off                    # the cloud table of the rows, when the launch needs one
+        ti = None
+        if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
+            ti = tile_segments(seg_rows, M, L.regtr_gemm_x3_tile_rows(M, N, K))
         check(L.regtr_gemm_x3(raw(a), lda, bptr(sw.planes), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
-                              int(planes), stream()), 'regtr_gemm_x3')
+                              int(planes), iptr(ti), stream()), 'regtr_gemm_x3')
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
             check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
@@ -171,6 +181,53 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     return out
 
 
+def tile_segments(seg_off, M, rows):
+    """(n_tiles, 4) int32 table of regtr_tile_segments for the rows described by `seg_off`, cached on the offsets tensor itself (one
+    tiny launch per pyramid level and tile height per forward)."""
+    cache = getattr(seg_off, '_regtr_tiles', None)
+    if cache is None:
+        cache = seg_off._regtr_tiles = {}
+    t = cache.get((M, rows))
+    if t is None:
+        t = torch.empty(((M + rows - 1) // rows, 4), dtype=torch.int32, device=seg_off.device)
+        check(_lib.lib().regtr_tile_segments(iptr(seg_off), seg_off.numel() - 1, M, rows, iptr(t), stream()), 'regtr_tile_segments')
+        cache[(M, rows)] = t
+    return t
+
+
+def stream_ok(M, N, K, a, a_stats=None):
+    """The one-shot strip kernel (csrc/gemm_stream.hip) serves this product and is the faster choice (tall problems only)."""
+    return bool(use_stream_gemm and not force_f32_gemm and not force_x3_gemm and M >= STREAM_MIN_ROWS and a.stride(1) == 1
+                and a.stride(0) % 4 == 0 and a.data_ptr() % 16 == 0 and (a_stats is None or K <= 64)
+                and _lib.lib().regtr_gemm_stream_supported(M, N, K))
+
+
+def gemm_stream(a, sw, seg_off, a_stats=None, a_slope=0.1, want_stats=False, eps=1e-5):
+    """regtr_gemm_stream: a' @ W for K in {32, 64, 128}, N <= 256 on millions of rows (see csrc/gemm_stream.hip).
+    want_stats: also return the per-cloud InstanceNorm (mean, rstd) table of the result.  -> out | (out, stats)"""
+    L = _lib.lib()
+    M, K = a.shape
+    N = sw.N
+    n_clouds = seg_off.numel() - 1
+    R = L.regtr_gemm_stream_tile_rows()
+    ti = tile_segments(seg_off, M, R)
+    partial = None
+    if want_stats:
+        partial = torch.empty((((M + R - 1) // R + n_clouds) * N, 2), dtype=torch.float64, device=a.device)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    check(L.regtr_gemm_stream(raw(a), a.stride(0) if M > 1 else K, bptr(sw.planes), ptr(out), N, M, N, K, ptr(a_stats), a_slope,
+                              iptr(seg_off), n_clouds, iptr(ti), dptr(partial), stream()), 'regtr_gemm_stream')
+    if not want_stats:
+        return out
+    stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
+    check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(seg_off), n_clouds, N, R, eps, ptr(stats), stream()),
+          'regtr_instnorm_finalize_tiles')
+    return out, stats
+
+
+STREAM_MIN_ROWS = 65536     # below this the tiled kernel's 2-D tiling fills the chip better than row strips do
+use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
+use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel
 force_x3_gemm = False       # tests: route every supported shape to the split kernel, also where it is not the faster one
 

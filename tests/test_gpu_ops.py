@@ -430,6 +430,35 @@ def test_mha_vs_oracle(lens, precision, tol):
     assert worst < tol
 
 
+STREAM_LENS = [[5000, 30000, 1, 0, 7, 33, 2100, 64, 64, 9000], [40000, 25000], [31, 1, 0, 2, 70000, 3], [100, 156, 3, 250]]
+
+
+@pytest.mark.parametrize('K,N', [(32, 128), (64, 128), (64, 256), (128, 32), (128, 64), (64, 32), (128, 128), (32, 32)])
+@pytest.mark.parametrize('lens', STREAM_LENS)
+def test_gemm_stream_vs_exact_f32(lens, K, N):
+    """regtr_gemm_stream (32-row strips from global memory straight into MFMA fragments, weights in LDS per 256-row workgroup,
+    per-tile float64 statistics): product vs the exact-f32 kernel, InstanceNorm statistics vs the stand-alone pass over the
+    result -- ragged clouds with empty / one-row clouds inside a tile, tile boundaries inside clouds; with and without the producer's
+    InstanceNorm+LeakyReLU folded into the A load (K <= 64)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(lens) + N + K)
+    M = sum(lens)
+    seg = seg_of(np.array(lens, np.int32))
+    a = (torch.randn(M, K, generator=g) * 2 + 0.5).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    sw = ops.SplitWeight(w, 'nk')
+    assert sw.planes is not None
+    for fold in ([False, True] if K <= 64 else [False]):
+        a_st = ops.instnorm_stats(a, seg, max(lens)) if fold else None
+        out, st = ops.gemm_stream(a, sw, seg, a_stats=a_st, want_stats=True)
+        ref = ops.gemm(a, w.t().contiguous(), a_stats=a_st, a_seg_off=seg if fold else None)       # exact-f32 MFMA kernel
+        assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), (K, N, fold)
+        assert torch.equal(out, ops.gemm_stream(a, sw, seg, a_stats=a_st))                          # without the statistics
+        rst = ops.instnorm_stats(out, seg, max(lens))
+        assert (st[..., 0] - rst[..., 0]).abs().max() <= 1e-6 * max(1.0, rst[..., 0].abs().max().item())
+        assert ((st[..., 1] - rst[..., 1]).abs() <= 2e-6 * rst[..., 1].abs() + 1e-30).all()
+
+
 @pytest.mark.parametrize('planes,tol', [(3, 3e-6), (2, 2e-4), (1, 2e-2)])
 def test_gemm_x3_plane_count(planes, tol, x3_forced):
     """regtr_gemm_x3 with 3 (float32-grade), 2 (three-term) and 1 (plain bf16) planes per operand vs float64, relative to the
