@@ -130,9 +130,13 @@ int regtr_kpconv_gather_computes_flag(int Cin, int H);
 
 /* wf [nq, KP*Cin] (kernel point major, channel minor), num [nq] = max(1, #positive neighbours).  nbr [nq,H] int32,
  * x [ns,Cin], flag [ns] (or NULL, see above), kernel_points [KP,3], KP <= 16.  x_stats [n_seg,Cin,2] + q_seg_off [n_seg+1] (optional): the
- * gathered features are LeakyReLU_slope(InstanceNorm(x)) computed on the fly (cloud of a neighbour = cloud of its query). */
+ * gathered features are LeakyReLU_slope(InstanceNorm(x)) computed on the fly (cloud of a neighbour = cloud of its query).
+ * s_xyzf (optional, 16-byte aligned [ns,4], no x_stats): per-support records (x, y, z, f) read with ONE 16-byte load per neighbour
+ * instead of four scattered 4-byte ones -- the gathers are bound by the texture-address path (TA ~76 % busy, 40 % of its lines were
+ * these dwords).  f = the positivity flag (regtr_instnorm_apply writes the records: x is then final, no fold, no row sums); for
+ * Cin == 1, f = the feature itself. */
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                        int Cin, const float* flag, const float* kernel_points, int KP, float extent,
+                        int Cin, const float* flag, const float* s_xyzf, const float* kernel_points, int KP, float extent,
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
                         void* stream);
 
@@ -144,9 +148,13 @@ int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_n
 size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C);
 int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int max_len, int C, float eps, float* stats,
                          void* ws, size_t ws_bytes, void* stream);
-/* y = act((x-mean)*rstd [+ residual | + (residual-rmean)*rrstd]); act: 0 none, 1 LeakyReLU(slope); y may alias x */
+/* y = act((x-mean)*rstd [+ residual | + (residual-rmean)*rrstd]); act: 0 none, 1 LeakyReLU(slope); y may alias x.
+ * row_positive (optional, C <= 256): [rows] 1.0 where sum_c y[row,c] > 0 -- KPConv's per-support normaliser flag
+ * (kpconv_blocks.py:409-410), ready for regtr_kpconv_gather's `flag`; with row_xyz [rows,3] it is written as 16-byte records
+ * [rows,4] = (x, y, z, flag) instead: regtr_kpconv_gather's `s_xyzf`. */
 int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int max_len, int C, const float* stats,
-                         const float* residual, const float* res_stats, int act, float slope, float* y, void* stream);
+                         const float* residual, const float* res_stats, int act, float slope, float* y, const float* row_xyz,
+                         float* row_positive, void* stream);
 
 /* ---- dense ------------------------------------------------------------------------------------------------- */
 

@@ -37,11 +37,11 @@ SIGNATURES = {
     'regtr_overlap_avgpool': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
-    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),
-    'regtr_instnorm_apply': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P]),
+    'regtr_instnorm_apply': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _F, _P, _P, _P, _P]),
     'regtr_gemm_f32_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_gemm_f32': (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P]),
     'regtr_gemm_x3_supported': (_I, [_I, _I, _I]),

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_rowsum_positive(const float* __restrict
 }
 
 struct GatherArgs {
-    const float* q_xyz; const float* s_xyz; const int* nbr; const float* x; const float* flag; const float* kp;
+    const float* q_xyz; const float* s_xyz; const int* nbr; const float* x; const float* flag; const float* s_xyzf; const float* kp;
     float* wf; float* num;
     const float2* x_stats; const int* q_seg_off;     // optional fused lrelu(InstanceNorm(x)) on the gathered features
     int nq, ns, H, Cin, KP, n_seg;
@@ -259,7 +259,11 @@ __device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned 
 #ifndef RG_MG_WAVES_PER_EU
 #define RG_MG_WAVES_PER_EU 3
 #endif
-template <int J, int V>    // J = ceil(H / 4) neighbour groups (H <= 4 J); V floats per lane per row per pass
+// PRE: g.s_xyzf holds (x, y, z, positivity flag) records and the features are final (no InstanceNorm fold) -- the launcher's choice
+// when the caller passes `s_xyzf` and no x_stats.  Per neighbour ONE 16-byte load replaces three coordinate dwords (plus the flag):
+// PMC on the level-0 launch showed the texture-address path 76 % busy, 148 of ~260 lines per query being those scattered dwords,
+// and waves 68 % of their time in issue stalls behind it; per query ~170 of ~290 VALU instructions (fold, row sums) go as well.
+template <int J, int V, bool PRE>    // J = ceil(H / 4) neighbour groups (H <= 4 J); V floats per lane per row per pass
 __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_kpconv_gather_mfma(GatherArgs g)
 {
     typedef typename RgVec<V>::type vec;
@@ -279,6 +283,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     const unsigned row_bytes = (unsigned)Cin * 4u;
     const __amdgpu_buffer_rsrc_t x_rs = rg_rsrc(g.x, (unsigned)ns * row_bytes);
     const __amdgpu_buffer_rsrc_t sxyz_rs = rg_rsrc(g.s_xyz, (unsigned)ns * 12u);
+    const __amdgpu_buffer_rsrc_t xyzf_rs = rg_rsrc(PRE ? g.s_xyzf : g.s_xyz, PRE ? (unsigned)ns * 16u : 0u);
     const unsigned lane_off = (unsigned)(V * k) * 4u;                 // this lane's channel bytes within a 16 V pass
     unsigned st_off[4];                                               // WF store offsets of the lane's 4 kernel-point rows
 #pragma unroll
@@ -296,17 +301,23 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
         const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + hl];
         return (q < nq && lane < H) ? v : ns;
     };
-    struct Nb { float rx, ry, rz; };
+    struct Nb { float rx, ry, rz, f; };
     auto load_nb = [&](int q, int idx) -> Nb {
         const bool real = idx < ns;                                  // else: shadow support point at 1e6 (kpconv_blocks.py:309)
-        const unsigned so = real ? (unsigned)idx * 12u : RG_OOB;
-        const float sx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so, 0, 0));
-        const float sy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 4u, 0, 0));
-        const float sz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 8u, 0, 0));
+        float sx, sy, sz, f = 0.f;
+        if (PRE) {
+            const rg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xyzf_rs, real ? (unsigned)idx * 16u : RG_OOB, 0, 0);
+            sx = __uint_as_float(r.x); sy = __uint_as_float(r.y); sz = __uint_as_float(r.z); f = __uint_as_float(r.w);
+        } else {
+            const unsigned so = real ? (unsigned)idx * 12u : RG_OOB;
+            sx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so, 0, 0));
+            sy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 4u, 0, 0));
+            sz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(sxyz_rs, so + 8u, 0, 0));
+        }
         const unsigned qc = (unsigned)(q < nq ? q : nq - 1);
         const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
         Nb n;
-        n.rx = (real ? sx : 1e6f) - qx; n.ry = (real ? sy : 1e6f) - qy; n.rz = (real ? sz : 1e6f) - qz;
+        n.rx = (real ? sx : 1e6f) - qx; n.ry = (real ? sy : 1e6f) - qy; n.rz = (real ? sz : 1e6f) - qz; n.f = f;
         return n;
     };
     // Software pipeline over the wave's queries: the index row of query q+2 and the neighbour coordinates of query q+1
@@ -342,7 +353,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
             row[j] = __float_as_uint(nb.w) + lane_off;
         }
         const float2* st = nullptr;
-        if (g.x_stats) {
+        if (!PRE && g.x_stats) {
             // q is wave-uniform and the wave's queries are consecutive: the cloud changes at most rarely, and when it does
             // the whole wave finds it in one round trip (a per-lane binary search would be log2(n) DEPENDENT loads here)
             if (q >= seg_end) {
@@ -354,6 +365,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
         const __amdgpu_buffer_rsrc_t wf_rs = rg_rsrc(g.wf + (size_t)q * g.KP * Cin, wf_q_bytes);
         Nb nb_nxt = nb_cur;
         int idx_nn = ns;
+        const float f_cur = nb_cur.f;
         float rsum[J];
 #pragma unroll
         for (int j = 0; j < J; j++) rsum[j] = 0.f;
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
                 nb_nxt = load_nb(q + 1, idx_nxt);
                 idx_nn = load_idx(q + 2);
             }
-            if (st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock (wave-uniform branch)
+            if (!PRE && st) {   // fused lrelu(InstanceNorm(x)) of the preceding UnaryBlock (wave-uniform branch)
                 float2 ms[V];
 #pragma unroll
                 for (int v = 0; v < V; v += 2) {
@@ -385,6 +397,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
             }
             // A shadow neighbour's row needs no zeroing for WF: its influence w is exactly 0 (it sits 1e6 away).  Its row
             // sum is discarded below.
+            if (!PRE)
 #pragma unroll
             for (int j = 0; j < J; j++) {   // partial row sums for the normaliser (:409)
                 float s = rg_comp(xv[j], 0);
@@ -410,10 +423,14 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
         }
         // ---- normaliser: positive-row count over the query's real neighbours   (:409-411)
         float cnt = 0.f;
+        if (PRE) {   // lanes = neighbours here (a lane beyond H or on a shadow neighbour loaded 0)
+            cnt = (float)__builtin_popcountll(__ballot(f_cur > 0.f));
+        } else {
 #pragma unroll
-        for (int j = 0; j < J; j++) cnt += (rg_row16_sum(rsum[j]) > 0.f && row[j] < RG_OOB) ? 1.f : 0.f;
-        cnt += __shfl_xor(cnt, 16, RG_WAVE);
-        cnt += __shfl_xor(cnt, 32, RG_WAVE);
+            for (int j = 0; j < J; j++) cnt += (rg_row16_sum(rsum[j]) > 0.f && row[j] < RG_OOB) ? 1.f : 0.f;
+            cnt += __shfl_xor(cnt, 16, RG_WAVE);
+            cnt += __shfl_xor(cnt, 32, RG_WAVE);
+        }
         if (lane == 0) g.num[q] = fmaxf(cnt, 1.f);
         idx_cur = idx_nxt; nb_cur = nb_nxt; idx_nxt = idx_nn;
     }
@@ -440,8 +457,13 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
             const int idx = g.nbr[(size_t)q * H + h];
             float sx = 1e6f, sy = 1e6f, sz = 1e6f;
             if (idx < g.ns) {
-                sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
-                x1 = g.x[idx]; f = g.flag ? g.flag[idx] : (x1 > 0.f ? 1.f : 0.f);
+                if (g.s_xyzf) {   // (x, y, z, feature) in one 16-byte load
+                    const float4 r = *(const float4*)(g.s_xyzf + 4 * (size_t)idx);
+                    sx = r.x; sy = r.y; sz = r.z; x1 = r.w; f = x1 > 0.f ? 1.f : 0.f;
+                } else {
+                    sx = g.s_xyz[3 * (size_t)idx]; sy = g.s_xyz[3 * (size_t)idx + 1]; sz = g.s_xyz[3 * (size_t)idx + 2];
+                    x1 = g.x[idx]; f = g.flag ? g.flag[idx] : (x1 > 0.f ? 1.f : 0.f);
+                }
             }
             rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
         }
@@ -520,16 +542,17 @@ int regtr_kpconv_gather_computes_flag(int Cin, int H) { return (Cin == 1 || (Cin
 
 // wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
-                        int Cin, const float* flag, const float* kernel_points, int KP, float extent,
+                        int Cin, const float* flag, const float* s_xyzf, const float* kernel_points, int KP, float extent,
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
                         void* stream)
 {
     if (!q_xyz || !s_xyz || !nbr || !x || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
-        Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f) || (x_stats && (!q_seg_off || n_seg < 1)))
+        Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f) || (x_stats && (!q_seg_off || n_seg < 1)) ||
+        (s_xyzf && (x_stats || (uintptr_t)s_xyzf % 16 || (long long)ns * 16 >= (1LL << 31))))
         return RG_ERR_ARG;
     if (!flag && !regtr_kpconv_gather_computes_flag(Cin, H)) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
-    GatherArgs g{q_xyz, s_xyz, nbr, x, flag, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
+    GatherArgs g{q_xyz, s_xyz, nbr, x, flag, s_xyzf, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
                  nq, ns, H, Cin, KP, n_seg, extent, slope};
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 1) {
@@ -545,10 +568,13 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
         const int grid_m = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * MG_QPW));
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
         const bool v4 = Cin % 64 == 0;
-#define RG_LAUNCH_MG(JJ) do { if (v4) k_kpconv_gather_mfma<JJ, 4><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); \
-                              else k_kpconv_gather_mfma<JJ, 2><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); } while (0)
+        const bool pre = s_xyzf != nullptr;
+#define RG_LAUNCH_MG2(JJ, VV) do { if (pre) k_kpconv_gather_mfma<JJ, VV, true><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); \
+                                   else k_kpconv_gather_mfma<JJ, VV, false><<<grid_m, GATHER_WAVES * RG_WAVE, 0, st>>>(g); } while (0)
+#define RG_LAUNCH_MG(JJ) do { if (v4) RG_LAUNCH_MG2(JJ, 4); else RG_LAUNCH_MG2(JJ, 2); } while (0)
         if (J == 10) RG_LAUNCH_MG(10); else if (J == 13) RG_LAUNCH_MG(13); else RG_LAUNCH_MG(16);
 #undef RG_LAUNCH_MG
+#undef RG_LAUNCH_MG2
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;
     }

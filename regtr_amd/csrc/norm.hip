@@ -117,7 +117,8 @@ __global__ void __launch_bounds__(256) k_instnorm_finalize_tiles(const double2* 
 __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
                                                         const float2* __restrict__ stats, const float* __restrict__ res,
                                                         const float2* __restrict__ res_stats, int act, float slope,
-                                                        float* __restrict__ y)
+                                                        float* __restrict__ y, const float* __restrict__ row_xyz,
+                                                        float* __restrict__ row_positive)
 {
     const int b = blockIdx.y, chunk = blockIdx.x;
     const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
@@ -157,6 +158,16 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
                 for (int j = 0; j < 4; j++) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
             }
             *(float4*)(y + (size_t)rr * C + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
+            if (row_positive) {   // C4 is a power of two <= 64 here: the row's lanes sit in one wave, aligned to C4
+                float sum = (o[0] + o[1]) + (o[2] + o[3]);
+                for (int m = 1; m < C4; m <<= 1) sum += __shfl_xor(sum, m, RG_WAVE);
+                if (tx == 0) {
+                    const float f = sum > 0.f ? 1.f : 0.f;
+                    if (row_xyz) *(float4*)(row_positive + 4 * (size_t)rr) = make_float4(row_xyz[3 * (size_t)rr], row_xyz[3 * (size_t)rr + 1],
+                                                                                         row_xyz[3 * (size_t)rr + 2], f);
+                    else row_positive[rr] = f;
+                }
+            }
         }
     }
 }
@@ -252,15 +263,19 @@ int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int
 }
 
 // y = act( (x - mean) * rstd  [+ residual | + (residual - rmean) * rrstd] ), act 1 = LeakyReLU(slope).
-// stats may be NULL (x used as is).  y may alias x.
+// stats may be NULL (x used as is).  y may alias x.  row_positive (optional, C <= 256): [rows] 1.0 where sum_c y[row, c] > 0 --
+// the per-support flag of KPConv's neighbour-count normaliser (kpconv_blocks.py:409-410), for regtr_kpconv_gather's `flag`; with
+// row_xyz [rows,3] it is written as 16-byte records [rows,4] = (x, y, z, flag), regtr_kpconv_gather's `s_xyzf`.
 int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int max_len, int C, const float* stats,
-                         const float* residual, const float* res_stats, int act, float slope, float* y, void* stream)
+                         const float* residual, const float* res_stats, int act, float slope, float* y, const float* row_xyz,
+                         float* row_positive, void* stream)
 {
     if (!x || !seg_off || !y || n_clouds < 1 || C < 4 || C % 4 || max_len < 0) return RG_ERR_ARG;
-    if (C > 1024 || 256 % (C / 4)) return RG_ERR_ARG;
+    if (C > 1024 || 256 % (C / 4) || (row_positive && C > 256) || (row_xyz && (!row_positive || (uintptr_t)row_positive % 16)))
+        return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
     k_instnorm_apply<<<dim3(rg_cdiv(max_len, IN_ROWS), n_clouds), 256, 0, (hipStream_t)stream>>>(
-        x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y);
+        x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y, row_xyz, row_positive);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -105,6 +105,8 @@ class Preprocessor(nn.Module):
         data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
                 '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
         want64 = bool(cfg.get('kpconv_meta_int64', False))
+        # stack_lengths of every level in one upload (they are already on the host) instead of two small kernels per level
+        stack_lengths = torch.from_numpy(np.diff(seg_host, axis=1).astype(np.int64)).to(device)
         for l in range(len(lv_points)):
             n_l = int(seg_host[l, -1])
             n_next = int(seg_host[l + 1, -1]) if l + 1 < len(lv_points) else 0
@@ -122,7 +124,7 @@ class Preprocessor(nn.Module):
             data['neighbors'].append(conv.long() if want64 else conv)
             data['pools'].append(pool.long() if want64 else pool)
             data['upsamples'].append(torch.zeros((0, 1), dtype=torch.int64, device=device))
-            data['stack_lengths'].append((lv_seg[l][1:] - lv_seg[l][:-1]).long())
+            data['stack_lengths'].append(stack_lengths[l])
         return data
 
 
@@ -150,11 +152,11 @@ class KPConv(nn.Module):
         self.kernel_points = nn.Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)   # :266
         self._cache = {}
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None, want_stats=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, x_stats=None, s_seg_off=None, q_seg_off=None, want_stats=None, xyzf=None):
         w = _prepared(self._cache, 'w', self.weights,
                       lambda p: ops.SplitWeight(p.view(self.K * self.in_channels, self.out_channels), 'kn'))
         return ops.kpconv(q_pts, s_pts, neighb_inds, x, w, self.kernel_points.detach(), self.KP_extent,
-                          x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off, want_stats=want_stats)
+                          x_stats=x_stats, s_seg_off=s_seg_off, q_seg_off=q_seg_off, want_stats=want_stats, xyzf=xyzf)
 
 
 class UnaryBlock(nn.Module):
@@ -209,7 +211,9 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, meta):
         v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
-        y, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, want_stats=(v.seg_post, v.max_post))
+        # one input feature per point (RegTR's ones): (x, y, z, feature) records, one 16-byte load per neighbour in the gather
+        xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather) else None
+        y, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, want_stats=(v.seg_post, v.max_post), xyzf=xyzf)
         return ops.instnorm_apply(y, v.seg_post, v.max_post, st, lrelu=True, out=y)
 
 
@@ -233,13 +237,21 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, meta):
         strided = 'strided' in self.block_name
         v = _LevelView(meta, self.layer_ind, strided)
-        # unary1 = Linear -> IN -> LReLU (:722): the IN+LReLU tail is applied on the fly inside the KPConv gather
+        # unary1 = Linear -> IN -> LReLU (:722).  The IN + LReLU tail runs once per support row, in place, and the same pass packs
+        # (x, y, z, "feature sum > 0" flag of KPConv's normaliser, :409-410) into 16-byte records: the gather then issues one load per
+        # neighbour instead of four scattered dwords (it is bound by the texture-address path) and neither folds nor sums rows.
+        # (ops.prenorm_gather = False: everything folded into the gather.)
+        xyzf = None
         if isinstance(self.unary1, UnaryBlock):
             x, x_st = self.unary1.linear(features, v.seg_pre, v.max_pre)
+            if ops.prenorm_gather and x.shape[1] <= 256:
+                xyzf = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
+                ops.instnorm_apply(x, v.seg_pre, v.max_pre, x_st, lrelu=True, out=x, row_xyz=v.s_pts, row_positive=xyzf)
+                x_st = None
         else:
             x, x_st = features, None
         x, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, x_stats=x_st, s_seg_off=v.seg_pre, q_seg_off=v.seg_post,
-                            want_stats=(v.seg_post, v.max_post))                                              # :726
+                            want_stats=(v.seg_post, v.max_post), xyzf=xyzf)                                   # :726
         # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
         y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
         shortcut = ops.maxpool(features, v.inds, v.pool_width) if strided else features                                     # :734-737

@@ -227,6 +227,7 @@ def gemm_stream(a, sw, seg_off, a_stats=None, a_slope=0.1, want_stats=False, eps
 
 STREAM_MIN_ROWS = 65536     # below this the tiled kernel's 2-D tiling fills the chip better than row strips do
 use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
+prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
 use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel
 force_x3_gemm = False       # tests: route every supported shape to the split kernel, also where it is not the faster one
@@ -265,24 +266,28 @@ def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
 
 # ------------------------------------------------------------------------------------------------ KPConv encoder
 def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_seg_off=None, q_seg_off=None, slope=0.1,
-           want_stats=None):
+           want_stats=None, xyzf=None):
     """KPConv.forward (kpconv_blocks.py:269-414), non-deformable / linear / sum.
     nbr (Nq,H) i32, x (Ns,Cin), w_flat (KP*Cin, Cout) -> (Nq, Cout).
     x_stats (n_clouds,Cin,2): the input features are LeakyReLU(InstanceNorm(x)) applied on the fly (the tail of the
     preceding UnaryBlock, kpconv_blocks.py:556-561), with s_seg_off / q_seg_off the support / query cloud offsets.
+    xyzf (Ns,4): (x, y, z, f) records of the supports, f = row-positivity of x as instnorm_apply(row_xyz=, row_positive=) writes
+    them (x final, no x_stats), or the feature itself when Cin == 1: one 16-byte load per neighbour in the gather.
     want_stats = (seg_off, max_len) of the QUERY rows: returns (out, InstanceNorm stats of out)."""
     L = _lib.lib()
+    assert xyzf is None or x_stats is None
     nq, H = nbr.shape
     ns, Cin = x.shape
     KP = kernel_points.shape[0]
     dev = x.device
     n_seg = s_seg_off.numel() - 1 if x_stats is not None else 0
-    flag = None
     # the matrix-core gather derives the positivity flags from the rows it reads; every other case (channel counts / row
     # widths it does not take, unaligned views, >= 2^29 feature elements, no supports) needs them precomputed
     fused_flag = (L.regtr_kpconv_gather_computes_flag(Cin, H) and x.data_ptr() % 16 == 0 and ns > 0 and ns * Cin < (1 << 29)
                   and (x_stats is None or x_stats.data_ptr() % 16 == 0))
+    flag = None
     if not fused_flag:
+        xyzf = None
         flag = torch.empty(ns, dtype=torch.float32, device=dev)
         check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), iptr(s_seg_off) if x_stats is not None else None, n_seg,
                                       slope, ptr(flag), stream()), 'regtr_rowsum_positive')
@@ -292,7 +297,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     if rec is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag),
+    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
                                 iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
           'regtr_kpconv_gather')
@@ -332,13 +337,17 @@ def instnorm_stats(x, seg_off, max_len, eps=1e-5):
     return stats
 
 
-def instnorm_apply(x, seg_off, max_len, stats, residual=None, res_stats=None, lrelu=False, slope=0.1, out=None):
+def instnorm_apply(x, seg_off, max_len, stats, residual=None, res_stats=None, lrelu=False, slope=0.1, out=None, row_positive=None,
+                   row_xyz=None):
+    """row_positive: optional (rows,) float32 output, 1.0 where the result's row sum is > 0 (KPConv's normaliser flag); with
+    row_xyz (rows,3) it is (rows,4) and receives (x, y, z, flag) records -- the `xyzf` operand of kpconv()."""
+    assert row_xyz is None or (row_positive is not None and row_positive.shape == (x.shape[0], 4) and row_xyz.shape == (x.shape[0], 3))
     n_clouds = seg_off.numel() - 1
     C = x.shape[1]
     if out is None:
         out = torch.empty_like(x)
     check(_lib.lib().regtr_instnorm_apply(ptr(x), iptr(seg_off), n_clouds, int(max_len), C, ptr(stats), ptr(residual),
-                                          ptr(res_stats), 1 if lrelu else 0, slope, ptr(out), stream()),
+                                          ptr(res_stats), 1 if lrelu else 0, slope, ptr(out), ptr(row_xyz), ptr(row_positive), stream()),
           'regtr_instnorm_apply')
     return out
 

@@ -326,6 +326,13 @@ def test_kpconv_vs_oracle(Cin, Cout, H):
                            torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(kp), extent)
     out = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), to_dev(x), to_dev(w.reshape(15 * Cin, Cout)), to_dev(kp), extent)
     assert (out.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
+    if Cin == 1:      # (x, y, z, feature) records, as the encoder's first block passes them
+        x[:] = rng.standard_normal((len(s), 1)).astype(np.float32)
+        ref = regtr_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64)),
+                               torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(kp), extent)
+        out = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), to_dev(x), to_dev(w.reshape(15 * Cin, Cout)), to_dev(kp), extent,
+                         xyzf=to_dev(np.concatenate([s, x], 1)))
+        assert (out.cpu() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 def test_fused_instnorm_paths_vs_oracle():
@@ -350,6 +357,26 @@ def test_fused_instnorm_paths_vs_oracle():
     out = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), to_dev(y), to_dev(w.reshape(15 * Cin, Cout)), to_dev(kp), 0.12,
                      x_stats=st, s_seg_off=seg_of(lens), q_seg_off=seg_of(ql))
     assert (out.cpu() - ref).abs().max() < 3e-5 * max(1.0, ref.abs().max().item())
+    # the form the encoder uses: IN + LReLU applied in place with the row flags as a by-product, gather without fold or row sums
+    for C2 in (32, 64, 128, 256):
+        y2 = (rng.standard_normal((len(s), C2)) * rng.uniform(0.2, 3, C2) + rng.uniform(-2, 2, C2)).astype(np.float32)
+        w3 = (rng.standard_normal((15, C2, 64)) / 30).astype(np.float32)
+        x2_ref = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(y2), L), 0.1)
+        ref3 = regtr_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64)), x2_ref,
+                                torch.from_numpy(w3), torch.from_numpy(kp), 0.12)
+        yd = to_dev(y2)
+        st3 = ops.instnorm_stats(yd, seg_of(lens), int(lens.max()))
+        flag = torch.full((len(s),), -1.0, device='cuda')
+        xyzf = torch.full((len(s), 4), -1.0, device='cuda')
+        ops.instnorm_apply(yd.clone(), seg_of(lens), int(lens.max()), st3, lrelu=True, row_positive=flag)
+        ops.instnorm_apply(yd, seg_of(lens), int(lens.max()), st3, lrelu=True, out=yd, row_xyz=to_dev(s), row_positive=xyzf)
+        assert torch.equal(xyzf[:, :3].cpu(), torch.from_numpy(s)) and torch.equal(xyzf[:, 3], flag)
+        assert (yd.cpu() - x2_ref).abs().max() < 2e-5
+        rs = x2_ref.double().sum(1)
+        sure = rs.abs() > 1e-4                                   # rows whose sign no summation order can flip
+        assert torch.equal(flag.cpu()[sure], (rs[sure] > 0).float()) and set(flag.cpu().unique().tolist()) <= {0.0, 1.0}
+        out3 = ops.kpconv(to_dev(q), to_dev(s), to_dev(idx), yd, to_dev(w3.reshape(15 * C2, 64)), to_dev(kp), 0.12, xyzf=xyzf)
+        assert (out3.cpu() - ref3).abs().max() < 3e-5 * max(1.0, ref3.abs().max().item())
     # GEMM with the normalisation folded into the A operand
     w2 = (rng.standard_normal((Cin, 96)) / 8).astype(np.float32)
     ref2 = x_ref @ torch.from_numpy(w2)

@@ -19,7 +19,10 @@ def main():
     ap.add_argument('--pairs', type=int, default=16)
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--no-fold', action='store_true', help='features already normalised: no InstanceNorm+LeakyReLU fold in the gather')
+    ap.add_argument('--pre', action='store_true', help='features final + precomputed row flags (the encoder\'s form): no fold, no row sums')
     args = ap.parse_args()
+    if args.pre:
+        args.no_fold = True
     dev = torch.device('cuda', 0)
     cfg = load_config(os.path.join(bench.ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
     pairs = [bench.synth_pair(i, 20000) for i in range(args.pairs)]
@@ -41,9 +44,10 @@ def main():
         x = torch.randn(ns, Cin, device=dev)
         st = ops.instnorm_stats(x, seg_s, max(meta['_lens_host'][layer]))
         wf = torch.empty(nq, 15 * Cin, device=dev); num = torch.empty(nq, device=dev)
+        flag = torch.cat((s_pts, (x.sum(1, keepdim=True) > 0).float()), 1).contiguous() if args.pre else None
 
         def run():
-            _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.iptr(nbr), H, _lib.ptr(x), Cin, None,
+            _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.iptr(nbr), H, _lib.ptr(x), Cin, None, _lib.ptr(flag),
                                              _lib.ptr(kp), 15, radius * 0.8, None if args.no_fold else _lib.ptr(st), None if args.no_fold else _lib.iptr(seg_q), 0 if args.no_fold else seg_q.numel() - 1, 0.1,
                                              _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
         for _ in range(3):
