@@ -203,6 +203,20 @@ int regtr_gemm_stream_tile_rows(void);
 int regtr_gemm_stream(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                       const float* a_stats, float a_slope, const int* seg_off, int n_seg, const void* tile_info,
                       double* stat_partial, void* stream);
+/* The tail of a resnet bottleneck block with a Linear shortcut in one pass over the block's narrow inputs (csrc/block_tail.hip;
+ * kpconv_blocks.py:727-741):  Y = LeakyReLU_slope( InstanceNorm(A1' W1) + InstanceNorm(A2 W2) ),
+ * A1' = LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats [n_clouds,K1,2].  The statistics of the two products come from the K x K
+ * second moments of their inputs (float64), so neither product is ever written: replaces unary2 GEMM + shortcut GEMM +
+ * regtr_instnorm_apply.  A1 [M,K1], A2 [M,K2], W1 [K1,N] / W2 [K2,N] float32 row-major, seg_off [n_clouds+1], max_len = longest
+ * cloud, tile_info = regtr_tile_segments(seg_off, n_clouds, M, 256, ..).  out_stats (optional) [2,n_clouds,N,2] receives the
+ * (mean, rstd) of the two products.  Served shapes: regtr_block_tail_supported. */
+int regtr_block_tail_supported(int M, int N, int K1, int K2);
+size_t regtr_block_tail_ws_bytes(int n_clouds, int max_len, int N, int K1, int K2);
+int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* A2, int lda2,
+                     const float* W1, const float* W2, const int* seg_off, int n_clouds, int max_len, const void* tile_info,
+                     int M, int N, int K1, int K2, float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes,
+                     float* out_stats, void* stream);
+
 /* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
  * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud
  * offsets of C's rows; then regtr_instnorm_finalize_tiles(stat_partial, seg_off, n_clouds, N, R, eps, stats) yields the

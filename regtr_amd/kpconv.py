@@ -252,6 +252,13 @@ class ResnetBottleneckBlock(nn.Module):
             x, x_st = features, None
         x, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, x_stats=x_st, s_seg_off=v.seg_pre, q_seg_off=v.seg_post,
                             want_stats=(v.seg_post, v.max_post), xyzf=xyzf)                                   # :726
+        # Linear shortcut on the same rows (not strided): the whole tail -- unary2, shortcut, both InstanceNorms, sum, LReLU -- in one
+        # pass over the two narrow inputs, statistics from their second moments (csrc/block_tail.hip)
+        if not strided and isinstance(self.unary_shortcut, UnaryBlock):
+            w2 = _prepared(self.unary2._cache, 'w', self.unary2.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
+            ws = _prepared(self.unary_shortcut._cache, 'w', self.unary_shortcut.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
+            if ops.block_tail_ok(x, st, features, w2, ws):
+                return ops.block_tail(x, st, features, w2, ws, v.seg_post, v.max_post)
         # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
         y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
         shortcut = ops.maxpool(features, v.inds, v.pool_width) if strided else features                                     # :734-737

@@ -225,8 +225,37 @@ def gemm_stream(a, sw, seg_off, a_stats=None, a_slope=0.1, want_stats=False, eps
     return out, stats
 
 
+def block_tail_ok(x1, x1_stats, f, sw1, sw2):
+    """regtr_block_tail serves this resnet-block tail (shape, alignment, size) and is switched on."""
+    M, K1 = x1.shape
+    return bool(use_block_tail and not force_f32_gemm and not force_x3_gemm and M >= STREAM_MIN_ROWS and f.shape[0] == M
+                and x1_stats is not None and sw1.N == sw2.N and x1.stride(1) == 1 and f.stride(1) == 1
+                and x1.stride(0) % 4 == 0 and f.stride(0) % 4 == 0 and x1.data_ptr() % 16 == 0 and f.data_ptr() % 16 == 0
+                and x1_stats.data_ptr() % 16 == 0 and _lib.lib().regtr_block_tail_supported(M, sw1.N, K1, f.shape[1]))
+
+
+def block_tail(x1, x1_stats, f, sw1, sw2, seg_off, max_len, slope=0.1, eps=1e-5, want_stats=False):
+    """LeakyReLU(InstanceNorm(x1' @ W1) + InstanceNorm(f @ W2)), x1' = LeakyReLU(InstanceNorm(x1)) by x1_stats: the tail of a resnet
+    bottleneck block with a Linear shortcut (kpconv_blocks.py:727-741) without writing either product (csrc/block_tail.hip).
+    sw1 / sw2: SplitWeight of unary2 / unary_shortcut.  want_stats: also return the (2, n_clouds, N, 2) (mean, rstd) of the products."""
+    L = _lib.lib()
+    M, K1 = x1.shape
+    K2, N = f.shape[1], sw1.N
+    n_clouds = seg_off.numel() - 1
+    nb = L.regtr_block_tail_ws_bytes(n_clouds, int(max_len), N, K1, K2)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x1.device)       # not the shared scratch: sized per call, used across four launches
+    ti = tile_segments(seg_off, M, 256)
+    y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
+    st = torch.empty((2, n_clouds, N, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    check(L.regtr_block_tail(raw(x1), x1.stride(0), ptr(x1_stats), slope, raw(f), f.stride(0), ptr(sw1.kn), ptr(sw2.kn),
+                             iptr(seg_off), n_clouds, int(max_len), iptr(ti), M, N, K1, K2, eps, slope, ptr(y), N, bptr(ws), nb,
+                             ptr(st), stream()), 'regtr_block_tail')
+    return (y, st) if want_stats else y
+
+
 STREAM_MIN_ROWS = 65536     # below this the tiled kernel's 2-D tiling fills the chip better than row strips do
 use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
+use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
 prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
 use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel

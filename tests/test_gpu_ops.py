@@ -486,6 +486,51 @@ def test_gemm_stream_vs_exact_f32(lens, K, N):
         assert ((st[..., 1] - rst[..., 1]).abs() <= 2e-6 * rst[..., 1].abs() + 1e-30).all()
 
 
+@pytest.mark.parametrize('lens', [[70000], [20000, 0, 33001, 12999], [300, 66000, 5], [1000] * 70])
+def test_block_tail_vs_separate_ops(lens):
+    """regtr_block_tail (statistics from input moments, neither product written) against unary2 GEMM + shortcut GEMM +
+    instnorm_apply, and its reported product statistics against float64."""
+    ops = _ops()
+    rng = np.random.default_rng(len(lens))
+    M, K1, K2, N = sum(lens), 32, 64, 128
+    seg = seg_of(lens)
+    x1 = (rng.standard_normal((M, K1)) * rng.uniform(0.3, 3, K1) + rng.uniform(-2, 2, K1)).astype(np.float32)
+    f = (rng.standard_normal((M, K2)) * rng.uniform(0.3, 2, K2) + rng.uniform(-1, 1, K2)).astype(np.float32)
+    f[:, 5] = 0.25 * f[:, 4] + 3.0                       # correlated and offset channels: the covariance terms matter
+    w1 = (rng.standard_normal((N, K1)) / math.sqrt(K1)).astype(np.float32)
+    w2 = (rng.standard_normal((N, K2)) / math.sqrt(K2)).astype(np.float32)
+    w2[7] *= 1e-3                                        # a nearly dead output column (eps dominates its rstd)
+    x1d, fd = to_dev(x1), to_dev(f)
+    sw1, sw2 = ops.SplitWeight(to_dev(w1), 'nk'), ops.SplitWeight(to_dev(w2), 'nk')
+    x1_st = ops.instnorm_stats(x1d, seg, max(lens))
+    assert ops.block_tail_ok(x1d, x1_st, fd, sw1, sw2)
+    y, st = ops.block_tail(x1d, x1_st, fd, sw1, sw2, seg, max(lens), want_stats=True)
+    prev = ops.use_stream_gemm
+    try:
+        for strip in (True, False):
+            ops.use_stream_gemm = strip
+            u, u_st = ops.gemm(x1d, sw1, a_stats=x1_st, a_seg_off=seg, want_stats=(seg, max(lens)))
+            sc, sc_st = ops.gemm(fd, sw2, want_stats=(seg, max(lens)))
+            ref = ops.instnorm_apply(u, seg, max(lens), u_st, residual=sc, res_stats=sc_st, lrelu=True)
+            assert (y - ref).abs().max().item() < 3e-5
+    finally:
+        ops.use_stream_gemm = prev
+    # statistics against float64 of the exact products
+    L = torch.tensor(lens)
+    from oracle import regtr_ref
+    xn = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(x1).double(), L), 0.1)
+    for k, prod in enumerate((xn @ torch.from_numpy(w1).double().t(), torch.from_numpy(f).double() @ torch.from_numpy(w2).double().t())):
+        o = 0
+        for c, n in enumerate(lens):
+            if n == 0:
+                continue
+            blk = prod[o:o + n]; o += n
+            mean, var = blk.mean(0), blk.var(0, unbiased=False)
+            got = st[k, c].cpu().double()
+            assert (got[:, 0] - mean).abs().max() < 2e-6 * max(1.0, mean.abs().max().item())
+            assert ((got[:, 1] - 1 / torch.sqrt(var + 1e-5)) / (1 / torch.sqrt(var + 1e-5))).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize('planes,tol', [(3, 3e-6), (2, 2e-4), (1, 2e-2)])
 def test_gemm_x3_plane_count(planes, tol, x3_forced):
     """regtr_gemm_x3 with 3 (float32-grade), 2 (three-term) and 1 (plain bf16) planes per operand vs float64, relative to the
