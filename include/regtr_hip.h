@@ -134,10 +134,11 @@ int regtr_kpconv_gather_computes_flag(int Cin, int H);
  * s_xyzf (optional, 16-byte aligned [ns,4], no x_stats): per-support records (x, y, z, f) read with ONE 16-byte load per neighbour
  * instead of four scattered 4-byte ones -- the gathers are bound by the texture-address path (TA ~76 % busy, 40 % of its lines were
  * these dwords).  f = the positivity flag (regtr_instnorm_apply writes the records: x is then final, no fold, no row sums); for
- * Cin == 1, f = the feature itself. */
+ * Cin == 1, f = the feature itself.  ld_wf: row stride of wf in floats, 0 = KP*Cin; only Cin == 1 takes another value (16: rows padded
+ * with zeros, the A operand of regtr_block_tail's first-block form). */
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
                         int Cin, const float* flag, const float* s_xyzf, const float* kernel_points, int KP, float extent,
-                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
+                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, int ld_wf, float* num,
                         void* stream);
 
 /* out[q,:] = max over the first H columns of row q of nbr (row stride ld_nbr >= H) of x[nbr[q,h],:], the shadow index
@@ -203,16 +204,19 @@ int regtr_gemm_stream_tile_rows(void);
 int regtr_gemm_stream(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                       const float* a_stats, float a_slope, const int* seg_off, int n_seg, const void* tile_info,
                       double* stat_partial, void* stream);
-/* The tail of a resnet bottleneck block with a Linear shortcut in one pass over the block's narrow inputs (csrc/block_tail.hip;
- * kpconv_blocks.py:727-741):  Y = LeakyReLU_slope( InstanceNorm(A1' W1) + InstanceNorm(A2 W2) ),
- * A1' = LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats [n_clouds,K1,2].  The statistics of the two products come from the K x K
- * second moments of their inputs (float64), so neither product is ever written: replaces unary2 GEMM + shortcut GEMM +
- * regtr_instnorm_apply.  A1 [M,K1], A2 [M,K2], W1 [K1,N] / W2 [K2,N] float32 row-major, seg_off [n_clouds+1], max_len = longest
- * cloud, tile_info = regtr_tile_segments(seg_off, n_clouds, M, 256, ..).  out_stats (optional) [2,n_clouds,N,2] receives the
- * (mean, rstd) of the two products.  Served shapes: regtr_block_tail_supported. */
+/* Linear -> InstanceNorm [+ Linear -> InstanceNorm of a second input] -> LeakyReLU in one pass over the NARROW inputs
+ * (csrc/block_tail.hip):  Y = LeakyReLU_slope( InstanceNorm(A1' W1) [+ InstanceNorm(A2 W2)] ).  The per-cloud statistics of a product
+ * come from the K x K second moments of its input (float64), so no product is ever written.  Two served forms
+ * (regtr_block_tail_supported):
+ *   K1 = 32, K2 = 64, N = 128: the tail of the level-0 resnet block (kpconv_blocks.py:727-741) -- replaces unary2 GEMM + shortcut
+ *     GEMM + regtr_instnorm_apply; A1' = LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats [n_clouds,K1,2] (the conv output's);
+ *   K1 = 16, K2 = 0, N = 64: the first block (:590-646), A1 = the Cin = 1 gather's WF rows at ld_wf = 16, A1' = A1 / row_div1[row]
+ *     (the neighbour count, :411), a1_stats / A2 / W2 NULL -- replaces contraction GEMM + statistics + regtr_instnorm_apply.
+ * W1 [K1,N] / W2 [K2,N] float32 row-major, seg_off [n_clouds+1], max_len = longest cloud, tile_info = regtr_tile_segments(seg_off,
+ * n_clouds, M, 256, ..).  out_stats (optional) [1 or 2,n_clouds,N,2] receives the (mean, rstd) of the products. */
 int regtr_block_tail_supported(int M, int N, int K1, int K2);
 size_t regtr_block_tail_ws_bytes(int n_clouds, int max_len, int N, int K1, int K2);
-int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* A2, int lda2,
+int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* row_div1, const float* A2, int lda2,
                      const float* W1, const float* W2, const int* seg_off, int n_clouds, int max_len, const void* tile_info,
                      int M, int N, int K1, int K2, float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes,
                      float* out_stats, void* stream);

@@ -37,7 +37,7 @@ SIGNATURES = {
     'regtr_overlap_avgpool': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
-    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _I, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_instnorm_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_instnorm_stats': (_I, [_P, _P, _I, _I, _I, _F, _P, _P, _Z, _P]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     'regtr_gemm_stream_tile_rows': (_I, []),
     'regtr_block_tail_supported': (_I, [_I, _I, _I, _I]),
     'regtr_block_tail_ws_bytes': (_Z, [_I, _I, _I, _I, _I]),
-    'regtr_block_tail': (_I, [_P, _I, _P, _F, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P, _P]),
+    'regtr_block_tail': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P, _P]),
     'regtr_gemm_stream': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P, _P]),
     'regtr_gemm_x3_stat_tile_rows': (_I, [_I, _I, _I]),
     'regtr_instnorm_finalize_tiles': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),

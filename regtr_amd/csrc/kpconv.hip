@@ -49,7 +49,7 @@ struct GatherArgs {
     const float* q_xyz; const float* s_xyz; const int* nbr; const float* x; const float* flag; const float* s_xyzf; const float* kp;
     float* wf; float* num;
     const float2* x_stats; const int* q_seg_off;     // optional fused lrelu(InstanceNorm(x)) on the gathered features
-    int nq, ns, H, Cin, KP, n_seg;
+    int nq, ns, H, Cin, KP, n_seg, ld_wf;
     float extent, slope;
 };
 
@@ -488,7 +488,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
         acc = fmaf(wv, xs_s[e], acc);
         cnt += flg_s[e];
     }
-    if (kvalid) g.wf[(size_t)q * g.KP + k] = acc;
+    if (k < g.ld_wf) g.wf[(size_t)q * g.ld_wf + k] = kvalid ? acc : 0.f;      // ld_wf = KP, or 16 with a zero pad column
     if (k == 0) g.num[q] = fmaxf(cnt, 1.f);
 }
 
@@ -543,9 +543,11 @@ int regtr_kpconv_gather_computes_flag(int Cin, int H) { return (Cin == 1 || (Cin
 // wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,
                         int Cin, const float* flag, const float* s_xyzf, const float* kernel_points, int KP, float extent,
-                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, float* num,
+                        const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, int ld_wf, float* num,
                         void* stream)
 {
+    if (ld_wf == 0) ld_wf = KP * Cin;
+    if (ld_wf != KP * Cin && !(Cin == 1 && ld_wf == KP_PAD)) return RG_ERR_ARG;
     if (!q_xyz || !s_xyz || !nbr || !x || !kernel_points || !wf || !num || nq < 0 || ns < 0 || H < 1 ||
         Cin < 1 || KP < 1 || KP > KP_PAD || !(extent > 0.f) || (x_stats && (!q_seg_off || n_seg < 1)) ||
         (s_xyzf && (x_stats || (uintptr_t)s_xyzf % 16 || (long long)ns * 16 >= (1LL << 31))))
@@ -553,7 +555,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     if (!flag && !regtr_kpconv_gather_computes_flag(Cin, H)) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
     GatherArgs g{q_xyz, s_xyz, nbr, x, flag, s_xyzf, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
-                 nq, ns, H, Cin, KP, n_seg, extent, slope};
+                 nq, ns, H, Cin, KP, n_seg, ld_wf, extent, slope};
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 1) {
         if (x_stats) return RG_ERR_ARG;

@@ -213,6 +213,13 @@ class SimpleBlock(nn.Module):
         v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
         # one input feature per point (RegTR's ones): (x, y, z, feature) records, one 16-byte load per neighbour in the gather
         xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather) else None
+        kp = self.KPConv
+        if x.shape[1] == 1 and ops.first_block_ok(v.q_pts.shape[0], 1, kp.K, kp.out_channels):
+            # contraction + InstanceNorm + LReLU in one pass over the gather's 16-float rows (csrc/block_tail.hip)
+            w16 = _prepared(kp._cache, 'w16', kp.weights,
+                            lambda p: torch.cat((p.view(kp.K, kp.out_channels), p.new_zeros(1, kp.out_channels)), 0).contiguous())
+            return ops.kpconv_norm_lrelu(v.q_pts, v.s_pts, v.inds, x, w16, kp.kernel_points.detach(), kp.KP_extent,
+                                         v.seg_post, v.max_post, xyzf=xyzf)
         y, st = self.KPConv(v.q_pts, v.s_pts, v.inds, x, want_stats=(v.seg_post, v.max_post), xyzf=xyzf)
         return ops.instnorm_apply(y, v.seg_post, v.max_post, st, lrelu=True, out=y)
 

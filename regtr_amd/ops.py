@@ -238,19 +238,45 @@ def block_tail(x1, x1_stats, f, sw1, sw2, seg_off, max_len, slope=0.1, eps=1e-5,
     """LeakyReLU(InstanceNorm(x1' @ W1) + InstanceNorm(f @ W2)), x1' = LeakyReLU(InstanceNorm(x1)) by x1_stats: the tail of a resnet
     bottleneck block with a Linear shortcut (kpconv_blocks.py:727-741) without writing either product (csrc/block_tail.hip).
     sw1 / sw2: SplitWeight of unary2 / unary_shortcut.  want_stats: also return the (2, n_clouds, N, 2) (mean, rstd) of the products."""
+    return _block_tail(x1, x1_stats, None, f, sw1.kn, sw2.kn, seg_off, max_len, slope, eps, want_stats)
+
+
+def _block_tail(x1, x1_stats, row_div, f, w1_kn, w2_kn, seg_off, max_len, slope, eps, want_stats):
     L = _lib.lib()
     M, K1 = x1.shape
-    K2, N = f.shape[1], sw1.N
+    K2, N = (f.shape[1] if f is not None else 0), w1_kn.shape[1]
     n_clouds = seg_off.numel() - 1
     nb = L.regtr_block_tail_ws_bytes(n_clouds, int(max_len), N, K1, K2)
     ws = torch.empty(nb, dtype=torch.uint8, device=x1.device)       # not the shared scratch: sized per call, used across four launches
     ti = tile_segments(seg_off, M, 256)
     y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
-    st = torch.empty((2, n_clouds, N, 2), dtype=torch.float32, device=x1.device) if want_stats else None
-    check(L.regtr_block_tail(raw(x1), x1.stride(0), ptr(x1_stats), slope, raw(f), f.stride(0), ptr(sw1.kn), ptr(sw2.kn),
-                             iptr(seg_off), n_clouds, int(max_len), iptr(ti), M, N, K1, K2, eps, slope, ptr(y), N, bptr(ws), nb,
-                             ptr(st), stream()), 'regtr_block_tail')
+    st = torch.empty((2 if K2 else 1, n_clouds, N, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    check(L.regtr_block_tail(raw(x1), x1.stride(0), ptr(x1_stats), slope, ptr(row_div), raw(f) if f is not None else None,
+                             f.stride(0) if f is not None else 0, ptr(w1_kn), ptr(w2_kn), iptr(seg_off), n_clouds, int(max_len),
+                             iptr(ti), M, N, K1, K2, eps, slope, ptr(y), N, bptr(ws), nb, ptr(st), stream()), 'regtr_block_tail')
     return (y, st) if want_stats else y
+
+
+def first_block_ok(nq, Cin, KP, Cout):
+    """kpconv_norm_lrelu serves the encoder's first block (one input feature, 15 kernel points, 64 outputs, a tall batch)."""
+    return bool(use_block_tail and not force_f32_gemm and not force_x3_gemm and Cin == 1 and KP == 15 and nq >= STREAM_MIN_ROWS
+                and _lib.lib().regtr_block_tail_supported(nq, Cout, 16, 0))
+
+
+def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_off, max_len, xyzf=None, slope=0.1, eps=1e-5,
+                      want_stats=False):
+    """SimpleBlock with one input feature (kpconv_blocks.py:590-646): KPConv -> InstanceNorm -> LeakyReLU.  The gather writes its
+    15 weighted sums per query as 16-float rows; the contraction, the InstanceNorm (statistics from the rows' 16 x 16 second
+    moments) and the LeakyReLU are one pass over them (regtr_block_tail, K2 = 0).  w16_kn: the (15, Cout) weights padded to (16, Cout)."""
+    L = _lib.lib()
+    nq, H = nbr.shape
+    ns = x.shape[0]
+    KP = kernel_points.shape[0]
+    wf = torch.empty((nq, 16), dtype=torch.float32, device=x.device)
+    num = torch.empty(nq, dtype=torch.float32, device=x.device)
+    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), 1, None, ptr(xyzf), ptr(kernel_points), KP,
+                                float(extent), None, None, 0, slope, ptr(wf), 16, ptr(num), stream()), 'regtr_kpconv_gather')
+    return _block_tail(wf, None, num, None, w16_kn, None, seg_off, max_len, slope, eps, want_stats)
 
 
 STREAM_MIN_ROWS = 65536     # below this the tiled kernel's 2-D tiling fills the chip better than row strips do
@@ -328,7 +354,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         e0.record()
     check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
-                                iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), ptr(num), stream()),
+                                iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), 0, ptr(num), stream()),
           'regtr_kpconv_gather')
     if rec is not None:
         e1.record()

@@ -531,6 +531,31 @@ def test_block_tail_vs_separate_ops(lens):
             assert ((got[:, 1] - 1 / torch.sqrt(var + 1e-5)) / (1 / torch.sqrt(var + 1e-5))).abs().max() < 1e-5
 
 
+def test_first_block_fused_vs_separate_ops():
+    """kpconv_norm_lrelu (gather -> 16-float rows -> contraction + InstanceNorm + LeakyReLU from the rows' second moments) against
+    kpconv + instnorm_apply, on a two-cloud batch tall enough for the fused path."""
+    from regtr_amd.kernel_points import K015_CENTER
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    clouds = [synth_cloud(rng, 40000), synth_cloud(rng, 30000) + 9.0]
+    s = np.concatenate(clouds).astype(np.float32); lens = np.array([40000, 30000], np.int32)
+    r = 0.06
+    x = np.ones((len(s), 1), np.float32)
+    w = (rng.standard_normal((15, 1, 64)) / 4).astype(np.float32)
+    kp = (K015_CENTER * r).astype(np.float32)
+    seg = seg_of(lens)
+    sd, xd, kpd = to_dev(s), to_dev(x), to_dev(kp)
+    idxd = ops.CellGrid(sd, seg, len(s), r).query(sd, seg, len(s), 40)        # (the search has its own tests)
+    assert ops.first_block_ok(len(s), 1, 15, 64)
+    y_ref, st = ops.kpconv(sd, sd, idxd, xd, to_dev(w.reshape(15, 64)), kpd, r * 0.8, want_stats=(seg, int(lens.max())))
+    y_ref = ops.instnorm_apply(y_ref, seg, int(lens.max()), st, lrelu=True)
+    w16 = to_dev(np.concatenate([w.reshape(15, 64), np.zeros((1, 64), np.float32)]))
+    for xyzf in (None, torch.cat((sd, xd), 1).contiguous()):
+        y, st2 = ops.kpconv_norm_lrelu(sd, sd, idxd, xd, w16, kpd, r * 0.8, seg, int(lens.max()), xyzf=xyzf, want_stats=True)
+        assert (y - y_ref).abs().max().item() < 3e-5
+        assert (st2[0] - st).abs().max().item() < 2e-5 * max(1.0, st.abs().max().item())
+
+
 @pytest.mark.parametrize('planes,tol', [(3, 3e-6), (2, 2e-4), (1, 2e-2)])
 def test_gemm_x3_plane_count(planes, tol, x3_forced):
     """regtr_gemm_x3 with 3 (float32-grade), 2 (three-term) and 1 (plain bf16) planes per operand vs float64, relative to the

@@ -49,7 +49,7 @@ def main():
         def run():
             _lib.check(L.regtr_kpconv_gather(_lib.ptr(q_pts), nq, _lib.ptr(s_pts), ns, _lib.iptr(nbr), H, _lib.ptr(x), Cin, None, _lib.ptr(flag),
                                              _lib.ptr(kp), 15, radius * 0.8, None if args.no_fold else _lib.ptr(st), None if args.no_fold else _lib.iptr(seg_q), 0 if args.no_fold else seg_q.numel() - 1, 0.1,
-                                             _lib.ptr(wf), _lib.ptr(num), _lib.stream()), 'gather')
+                                             _lib.ptr(wf), 0, _lib.ptr(num), _lib.stream()), 'gather')
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
