@@ -212,7 +212,7 @@ class SimpleBlock(nn.Module):
     def forward(self, x, meta):
         v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
         # one input feature per point (RegTR's ones): (x, y, z, feature) records, one 16-byte load per neighbour in the gather
-        xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather) else None
+        xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather and x.shape[0] >= ops.PRENORM_MIN_ROWS) else None
         kp = self.KPConv
         if x.shape[1] == 1 and ops.first_block_ok(v.q_pts.shape[0], 1, kp.K, kp.out_channels):
             # contraction + InstanceNorm + LReLU in one pass over the gather's 16-float rows (csrc/block_tail.hip)
@@ -251,7 +251,7 @@ class ResnetBottleneckBlock(nn.Module):
         xyzf = None
         if isinstance(self.unary1, UnaryBlock):
             x, x_st = self.unary1.linear(features, v.seg_pre, v.max_pre)
-            if ops.prenorm_gather and x.shape[1] <= 256:
+            if ops.prenorm_gather and x.shape[1] <= 256 and x.shape[0] >= ops.PRENORM_MIN_ROWS:   # (small batches: launch-bound, fold)
                 xyzf = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
                 ops.instnorm_apply(x, v.seg_pre, v.max_pre, x_st, lrelu=True, out=x, row_xyz=v.s_pts, row_positive=xyzf)
                 x_st = None

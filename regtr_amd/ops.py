@@ -279,9 +279,10 @@ def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_o
     return _block_tail(wf, None, num, None, w16_kn, None, seg_off, max_len, slope, eps, want_stats)
 
 
-STREAM_MIN_ROWS = 65536     # below this the tiled kernel's 2-D tiling fills the chip better than row strips do
+STREAM_MIN_ROWS = 131072     # below this a forward is launch-bound (a pair or two): the tiled kernels and separate passes are as fast
 use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
 use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
+PRENORM_MIN_ROWS = 65536        # below this a forward is launch-bound: the extra normalise pass costs more than the gather saves
 prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
 use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel

@@ -503,7 +503,7 @@ def test_block_tail_vs_separate_ops(lens):
     x1d, fd = to_dev(x1), to_dev(f)
     sw1, sw2 = ops.SplitWeight(to_dev(w1), 'nk'), ops.SplitWeight(to_dev(w2), 'nk')
     x1_st = ops.instnorm_stats(x1d, seg, max(lens))
-    assert ops.block_tail_ok(x1d, x1_st, fd, sw1, sw2)
+    assert ops.block_tail_ok(x1d, x1_st, fd, sw1, sw2) == (M >= ops.STREAM_MIN_ROWS)      # (the size gate is a speed choice)
     y, st = ops.block_tail(x1d, x1_st, fd, sw1, sw2, seg, max(lens), want_stats=True)
     prev = ops.use_stream_gemm
     try:
@@ -546,7 +546,7 @@ def test_first_block_fused_vs_separate_ops():
     seg = seg_of(lens)
     sd, xd, kpd = to_dev(s), to_dev(x), to_dev(kp)
     idxd = ops.CellGrid(sd, seg, len(s), r).query(sd, seg, len(s), 40)        # (the search has its own tests)
-    assert ops.first_block_ok(len(s), 1, 15, 64)
+    assert ops.first_block_ok(len(s), 1, 15, 64) == (len(s) >= ops.STREAM_MIN_ROWS)
     y_ref, st = ops.kpconv(sd, sd, idxd, xd, to_dev(w.reshape(15, 64)), kpd, r * 0.8, want_stats=(seg, int(lens.max())))
     y_ref = ops.instnorm_apply(y_ref, seg, int(lens.max()), st, lrelu=True)
     w16 = to_dev(np.concatenate([w.reshape(15, 64), np.zeros((1, 64), np.float32)]))
