@@ -50,6 +50,13 @@ class Preprocessor(nn.Module):
         self.cfg = cfg
 
     def forward(self, pts: List[torch.Tensor]):
+        return self.finish(self.enqueue(pts))
+
+    def enqueue(self, pts: List[torch.Tensor], level0_event=None):
+        """Enqueues the whole pyramid on the current stream without touching the host (default order only; the parity mode's KD-tree
+        reads its row widths back).  level0_event: recorded as soon as level 0's conv table is complete -- everything the level-0
+        blocks need (RegTR.forward starts them on its main stream while the rest of the pyramid is still being built on this one).
+        -> state for finish() / level0_meta()."""
         cfg = self.cfg
         limits = cfg.neighborhood_limits
         device = pts[0].device
@@ -83,6 +90,8 @@ class Preprocessor(nn.Module):
                 grid = ops.CellGrid(points, seg, cap, r_normal)
                 if layer_blocks:
                     conv_i = grid.query(points, seg, cap, K)                             # :349-351
+                if layer == 0 and level0_event is not None:
+                    level0_event.record()
                 if strided:
                     pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)          # :366
                     pool_i = grid.query(pool_p, pool_seg, cap, K)                        # :376
@@ -99,8 +108,21 @@ class Preprocessor(nn.Module):
             r_normal *= 2
             layer += 1
             layer_blocks = []
+        return {'lens0': lens0, 'device': device, 'ref_order': ref_order, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
+                'lv_pool': lv_pool, 'lv_width': lv_width}
 
-        # the one host round trip: level sizes
+    @staticmethod
+    def level0_meta(state):
+        """What the level-0, non-strided blocks read from kpconv_meta (kpconv.py: _LevelView) -- all sizes are the inputs' own, so it
+        exists before the pyramid's level sizes have been read back."""
+        return {'points': [state['lv_points'][0]], '_neighbors_i32': [state['lv_conv'][0]], '_seg_off': [state['lv_seg'][0]],
+                '_lens_host': [state['lens0']]}
+
+    def finish(self, state):
+        """The one host round trip (level sizes) and the kpconv_meta dictionary."""
+        cfg = self.cfg
+        device, ref_order = state['device'], state['ref_order']
+        lv_points, lv_seg, lv_conv, lv_pool, lv_width = (state[k] for k in ('lv_points', 'lv_seg', 'lv_conv', 'lv_pool', 'lv_width'))
         seg_host = torch.stack(lv_seg).cpu().numpy()                                     # (levels, n_clouds + 1)
         data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
                 '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
@@ -313,10 +335,22 @@ class KPFEncoder(nn.Module):
             self.encoder_skips.append(block_i)
             self.encoder_skip_dims.append(in_dim)
 
-    def forward(self, x, batch):
-        skip_x = []
+    def forward(self, x, batch, start=0, stop=None, skip_x=None):
+        """Blocks [start, stop) (all by default); skip_x carries the skip list across a split call."""
+        skip_x = [] if skip_x is None else skip_x
         for block_i, block_op in enumerate(self.encoder_blocks):
+            if block_i < start or (stop is not None and block_i >= stop):
+                continue
             if block_i in self.encoder_skips:
                 skip_x.append(x)
             x = block_op(x, batch)
         return x, skip_x
+
+    def level0_blocks(self):
+        """Number of leading blocks that work on level 0 only (not strided): they need nothing but level 0's conv table."""
+        n = 0
+        for b in self.encoder_blocks:
+            if getattr(b, 'layer_ind', None) != 0 or 'strided' in b.block_name or 'pool' in b.block_name:
+                break
+            n += 1
+        return n

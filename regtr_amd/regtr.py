@@ -11,6 +11,7 @@ sizes after preprocessing): preprocess -> KPConv encoder -> feat_proj -> 6 cross
 correspondence head -> fused weighted-Procrustes.
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -35,6 +36,11 @@ class PositionEmbeddingCoordsSine(nn.Module):
 
     def forward(self, xyz):
         return ops.posemb_sine(xyz, self.d_model, self.scale, self.temperature)
+
+
+# A-B switch and size gate of the two-stream forward (RegTR._forward)
+overlap_preprocessing = os.environ.get('REGTR_OVERLAP', '1') != '0'
+OVERLAP_MIN_POINTS = 131072
 
 
 class CorrespondenceRegressor(nn.Module):
@@ -169,16 +175,43 @@ class RegTR(nn.Module):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if _TIMEIT else None
         if ev: ev[0].record()
 
-        # ---- preprocess (regtr.py:117-122)
-        kpconv_meta = self.preprocessor(batch['src_xyz'] + batch['tgt_xyz'])
-        batch['kpconv_meta'] = kpconv_meta
+        # ---- preprocess (regtr.py:117-122) + KPConv encoder (regtr.py:136)
+        clouds = batch['src_xyz'] + batch['tgt_xyz']
+        n0 = sum(int(p.shape[0]) for p in clouds)
+        n_l0 = self.kpf_encoder.level0_blocks()
+        if (overlap_preprocessing and n0 >= OVERLAP_MIN_POINTS and n_l0 > 0 and not ev
+                and not self.cfg.get('kpconv_ref_row_order', False)):
+            # Large batches: the pyramid is built on a second HIP stream, and the level-0 blocks -- which need only level 0's conv
+            # table and sizes the host already knows -- start on the main stream as soon as that table exists: the other 2.4 ms of
+            # pyramid building (latency-bound small kernels) run under 6 ms of bandwidth-bound level-0 convolution.
+            main = torch.cuda.current_stream()
+            side = _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
+            ev0 = torch.cuda.Event()
+            side.wait_stream(main)                                   # the inputs
+            with torch.cuda.stream(side):
+                state = self.preprocessor.enqueue(clouds, level0_event=ev0)
+            meta0 = self.preprocessor.level0_meta(state)
+            for t in (meta0['points'][0], meta0['_neighbors_i32'][0], meta0['_seg_off'][0]):
+                t.record_stream(main)                                # allocated on `side`, read on `main`
+            main.wait_event(ev0)
+            feats0 = torch.ones_like(meta0['points'][0][:, 0:1])
+            x, skips = self.kpf_encoder(feats0, meta0, 0, n_l0)
+            with torch.cuda.stream(side):                            # the size read-back waits for `side` only, not for level 0's blocks
+                kpconv_meta = self.preprocessor.finish(state)
+            main.wait_stream(side)
+            for key in ('points', 'neighbors', 'pools', '_neighbors_i32', '_pools_i32', '_seg_off', 'stack_lengths', 'upsamples'):
+                for t in kpconv_meta[key]:
+                    t.record_stream(main)
+            batch['kpconv_meta'] = kpconv_meta
+            feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
+        else:
+            kpconv_meta = self.preprocessor(clouds)
+            batch['kpconv_meta'] = kpconv_meta
+            feats0 = torch.ones_like(kpconv_meta['points'][0][:, 0:1])
+            if ev: ev[1].record()
+            feats_un, _ = self.kpf_encoder(feats0, kpconv_meta)
         slens_c = kpconv_meta['_lens_host'][-1]
         src_slens_c, tgt_slens_c = slens_c[:B], slens_c[B:]
-        feats0 = torch.ones_like(kpconv_meta['points'][0][:, 0:1])
-        if ev: ev[1].record()
-
-        # ---- KPConv encoder (regtr.py:136)
-        feats_un, _ = self.kpf_encoder(feats0, kpconv_meta)
         if ev: ev[2].record()
 
         # ---- projection, positional embedding, cross-encoder on packed tokens (regtr.py:145-166)
