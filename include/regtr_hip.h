@@ -25,7 +25,10 @@
  *   regtr_gemm_f32            KPConv.forward                      models/backbone_kpconv/kpconv_blocks.py:269-414
  *   regtr_maxpool_gather      max_pool                            kpconv_blocks.py:127-143
  *   regtr_instnorm_*          BatchNormBlock (InstanceNorm1d) + LeakyReLU + residual   kpconv_blocks.py:497-519,556-561,741
- *   regtr_gemm_f32 / _x3      nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
+ *   regtr_gemm_f32 / _x3 /
+ *   regtr_gemm_stream         nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
+ *   regtr_block_tail          ResnetBottleneckBlock tail (unary2 + unary_shortcut + sum + LeakyReLU), SimpleBlock after its gather
+ *                                                                 kpconv_blocks.py:727-741, 590-646
  *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
  *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
  *   regtr_mha_fwd             nn.MultiheadAttention core          transformers.py:197-226
