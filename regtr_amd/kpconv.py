@@ -108,8 +108,13 @@ class Preprocessor(nn.Module):
             r_normal *= 2
             layer += 1
             layer_blocks = []
+        # the level sizes travel to pinned host memory behind the last kernel; `done` is all a consumer (host or stream) waits for
+        seg_pin = torch.empty((len(lv_seg), len(lens0) + 1), dtype=torch.int32, pin_memory=True)
+        seg_pin.copy_(torch.stack(lv_seg), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
         return {'lens0': lens0, 'device': device, 'ref_order': ref_order, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
-                'lv_pool': lv_pool, 'lv_width': lv_width}
+                'lv_pool': lv_pool, 'lv_width': lv_width, 'seg_pin': seg_pin, 'done': done}
 
     @staticmethod
     def level0_meta(state):
@@ -119,11 +124,15 @@ class Preprocessor(nn.Module):
                 '_lens_host': [state['lens0']]}
 
     def finish(self, state):
-        """The one host round trip (level sizes) and the kpconv_meta dictionary."""
+        """The one host round trip (level sizes) and the kpconv_meta dictionary.  Runs on the CONSUMER's stream: it waits for the
+        pyramid's `done` event only, so a pyramid enqueued on another stream (RegTR's side stream, a prefetch for the next batch)
+        does not drag that stream's later work in."""
         cfg = self.cfg
         device, ref_order = state['device'], state['ref_order']
         lv_points, lv_seg, lv_conv, lv_pool, lv_width = (state[k] for k in ('lv_points', 'lv_seg', 'lv_conv', 'lv_pool', 'lv_width'))
-        seg_host = torch.stack(lv_seg).cpu().numpy()                                     # (levels, n_clouds + 1)
+        state['done'].synchronize()                                                      # host: the sizes have landed
+        torch.cuda.current_stream().wait_event(state['done'])                            # stream: the tables are complete
+        seg_host = state['seg_pin'].numpy()                                              # (levels, n_clouds + 1)
         data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
                 '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
         want64 = bool(cfg.get('kpconv_meta_int64', False))

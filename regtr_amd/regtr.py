@@ -148,6 +148,16 @@ class RegTR(nn.Module):
         self._params_checked = False
         return super().load_state_dict(*args, **kwargs)
 
+    def _side_stream(self, dev):
+        return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
+
+    @staticmethod
+    def _record_meta(meta, stream):
+        """Pyramid tensors are allocated on the side stream and read on `stream`: tell the caching allocator."""
+        for key in ('points', 'neighbors', 'pools', '_neighbors_i32', '_pools_i32', '_seg_off'):
+            for t in meta[key]:
+                t.record_stream(stream)
+
     @property
     def device(self):
         return next(self.parameters()).device
@@ -185,7 +195,7 @@ class RegTR(nn.Module):
             # table and sizes the host already knows -- start on the main stream as soon as that table exists: the other 2.4 ms of
             # pyramid building (latency-bound small kernels) run under 6 ms of bandwidth-bound level-0 convolution.
             main = torch.cuda.current_stream()
-            side = _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
+            side = self._side_stream(dev)
             ev0 = torch.cuda.Event()
             side.wait_stream(main)                                   # the inputs
             with torch.cuda.stream(side):
@@ -196,12 +206,8 @@ class RegTR(nn.Module):
             main.wait_event(ev0)
             feats0 = torch.ones_like(meta0['points'][0][:, 0:1])
             x, skips = self.kpf_encoder(feats0, meta0, 0, n_l0)
-            with torch.cuda.stream(side):                            # the size read-back waits for `side` only, not for level 0's blocks
-                kpconv_meta = self.preprocessor.finish(state)
-            main.wait_stream(side)
-            for key in ('points', 'neighbors', 'pools', '_neighbors_i32', '_pools_i32', '_seg_off', 'stack_lengths', 'upsamples'):
-                for t in kpconv_meta[key]:
-                    t.record_stream(main)
+            kpconv_meta = self.preprocessor.finish(state)            # host + main wait for the pyramid's `done` event only
+            self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
         else:

@@ -87,6 +87,34 @@ def test_stress_100k_forward_invariants():
     assert 1000 < len(one['src_kp'][0]) < 8000                                              # ~2k tokens per cloud at this size
 
 
+def test_two_stream_forward_equals_sequential():
+    """A large batch reaches the encoder two ways -- pyramid on the current stream, or pyramid on the side stream with the level-0 blocks
+    started early: the same kernels on the same data, identical outputs."""
+    from regtr_amd import RegTR, regtr
+    src, tgt = _pair()
+    cfg = load_cfg('3dmatch')
+    model = RegTR(cfg)
+    model.load_state_dict(seeded_sd(cfg))
+    model = model.cuda().eval()
+    mk = lambda: {'src_xyz': [torch.from_numpy(src).cuda(), torch.from_numpy(src[:40000]).cuda()],
+                  'tgt_xyz': [torch.from_numpy(tgt).cuda(), torch.from_numpy(tgt[:30000]).cuda()]}
+    assert sum(len(x) for x in (src, tgt)) >= regtr.OVERLAP_MIN_POINTS
+    prev = regtr.overlap_preprocessing
+    try:
+        regtr.overlap_preprocessing = False
+        b0 = mk(); ref = model(b0)
+        regtr.overlap_preprocessing = True
+        b1 = mk(); two = model(b1)
+    finally:
+        regtr.overlap_preprocessing = prev
+    assert torch.equal(two['pose'], ref['pose'])
+    for k in ('src_kp', 'tgt_kp', 'src_kp_warped', 'tgt_overlap'):
+        assert all(torch.equal(x, y) for x, y in zip(two[k], ref[k])), k
+    for l in range(len(b0['kpconv_meta']['points'])):
+        assert torch.equal(b1['kpconv_meta']['neighbors'][l], b0['kpconv_meta']['neighbors'][l])
+        assert torch.equal(b1['kpconv_meta']['stack_lengths'][l], b0['kpconv_meta']['stack_lengths'][l])
+
+
 def _ref_canonical_meta(pts_list, cfg):
     """kpconv_meta in the product's canonical orders at stress size: first-appearance subsampling from the (linear-time) C++
     oracle, neighbour sets from the unmodified reference C++ (KD-tree) re-ordered to (d2, index) and cut at K."""
