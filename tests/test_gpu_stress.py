@@ -115,6 +115,35 @@ def test_two_stream_forward_equals_sequential():
         assert torch.equal(b1['kpconv_meta']['stack_lengths'][l], b0['kpconv_meta']['stack_lengths'][l])
 
 
+def test_large_batch_paths_agree_with_per_op_paths():
+    """Strip GEMMs, moments tails, packed-record gather and the two-stream forward (all gated on batch size) against the plain per-op
+    paths, same weights and batch: they reorder float32 sums, nothing else -- poses / correspondences within 1e-4 (measured ~1e-5)."""
+    from regtr_amd import RegTR, ops, regtr
+    from regtr_amd.synthetic import synth_pair
+    cfg = load_cfg('3dmatch')
+    model = RegTR(cfg)
+    model.load_state_dict(seeded_sd(cfg))
+    model = model.cuda().eval()
+    pairs = [synth_pair(500 + i, 20000) for i in range(8)]
+    assert sum(len(s_) + len(t_) for s_, t_ in pairs) >= max(ops.STREAM_MIN_ROWS, regtr.OVERLAP_MIN_POINTS)
+    mk = lambda: {'src_xyz': [torch.from_numpy(s_).cuda() for s_, _ in pairs], 'tgt_xyz': [torch.from_numpy(t_).cuda() for _, t_ in pairs]}
+    prev = (ops.use_block_tail, ops.use_stream_gemm, ops.prenorm_gather, regtr.overlap_preprocessing)
+    try:
+        outs = []
+        for on in (True, False):
+            ops.use_block_tail = ops.use_stream_gemm = ops.prenorm_gather = regtr.overlap_preprocessing = on
+            outs.append(model(mk()))
+    finally:
+        ops.use_block_tail, ops.use_stream_gemm, ops.prenorm_gather, regtr.overlap_preprocessing = prev
+    new, old = outs
+    assert all(torch.equal(a, b) for a, b in zip(new['src_kp'], old['src_kp']))
+    assert (new['pose'] - old['pose']).abs().max() < 1e-4
+    for k in ('src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap'):
+        assert max(float((a - b).abs().max()) for a, b in zip(new[k], old[k])) < 1e-4, k
+    scale = max(1.0, max(float(b.abs().max()) for b in old['src_feat_un']))
+    assert max(float((a - b).abs().max()) for a, b in zip(new['src_feat_un'], old['src_feat_un'])) < 1e-4 * scale
+
+
 def _ref_canonical_meta(pts_list, cfg):
     """kpconv_meta in the product's canonical orders at stress size: first-appearance subsampling from the (linear-time) C++
     oracle, neighbour sets from the unmodified reference C++ (KD-tree) re-ordered to (d2, index) and cut at K."""
