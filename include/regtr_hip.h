@@ -72,18 +72,23 @@ size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds);
 int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds, int ns_cap, float radius, void* ws,
                          size_t ws_bytes, void* stream);
 
-/* Fixed-radius neighbours within the same cloud.  out_idx [nq_cap,K]: ascending (d2, support index), strict d2 < r2
- * in the reference's float32 arithmetic, padded with Ns_total = s_seg_off[n_clouds].  out_count [nq_cap] (optional):
+/* Fixed-radius neighbours within the same cloud, strict d2 < r2 in the reference's float32 arithmetic, rows padded with
+ * Ns_total = s_seg_off[n_clouds].  out_idx [nq_cap,K]:
+ *   order 0  the K NEAREST supports in the ball, ascending (d2, support index) -- the reference's CPU Preprocessor
+ *            (nanoflann radius search + sort, kpconv.py:243-258; cpp_neighbors/neighbors.cpp:211-332);
+ *   order 1  the FIRST K supports in the ball by support index, ascending by index -- the reference's PreprocessorGPU
+ *            (pytorch3d ball_query, kpconv.py:261-288), the class its model instantiates (regtr.py:29).
+ * The two differ only on rows whose ball holds more than K supports.  out_count [nq_cap] (optional):
  * untruncated in-ball count; out_max_count (optional, device int zeroed by the caller): max over out_count, i.e. the
  * row width the reference's batch_query would return.  1 <= K <= 448.  ns_cap / ws_bytes as given to the build. */
 int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
-                       int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
+                       int n_clouds, float radius, int K, int order, const void* grid_ws, size_t ws_bytes, int* out_idx,
                        int* out_count, int* out_max_count, void* stream);
 
 /* The same table for the grid's OWN supports as queries (every conv table of the pyramid): a cell-centric kernel -- one wave
  * per occupied cell stages the 27 neighbouring runs once in LDS and answers all of the cell's queries from there.  out_idx
  * [ns_cap, K] is indexed by the original support row; results are identical to regtr_radius_query(s_xyz, s_seg_off, ...). */
-int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, const void* grid_ws,
+int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, int order, const void* grid_ws,
                             size_t ws_bytes, int* out_idx, int* out_count, int* out_max_count, void* stream);
 
 /* ---- ground-truth overlap (training / validation side) ------------------------------------------- */

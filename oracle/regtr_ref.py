@@ -40,6 +40,8 @@ def preprocess(pts_list, cfg, use_ref_cpp=False):
     layer, layer_blocks = 0, []
 
     def radius(q, s, ql, sl, r, K):
+        if cfg.get('kpconv_neighbor_order', 'nearest') == 'index':          # PreprocessorGPU's neighbour sets (kpconv.py:261-288)
+            return ball_query_first_k(q, s, ql, sl, r, K)
         if use_ref_cpp:
             t = native.ref_batch_query(q, s, ql, sl, r)[:, :K]             # kpconv.py:254-256
             return t
@@ -400,4 +402,26 @@ def regtr_forward(sd, cfg, src_list, tgt_list, meta=None, use_ref_cpp=False, tim
     t3 = time.perf_counter()
     if timings is not None:
         timings.append((t1 - t0, t2 - t1, t3 - t2))
+    return out
+
+
+def ball_query_first_k(queries, supports, q_lens, s_lens, radius, K):
+    """The neighbour table of the reference's PreprocessorGPU (batch_neighbors_kpconv_gpu, kpconv.py:261-288): per query the FIRST K
+    supports of its own cloud with d2 < radius^2, in support-index order, padded with the total number of supports -- pytorch3d
+    ball_query's documented behaviour (it walks the supports in order and stops at K; float32 d2 = sum of squared differences).
+    PARITY UNPINNED: pytorch3d is not installable here, so this restates its documentation / kernel, not its output.
+    numpy arrays in, (Nq, K) int64 out."""
+    import numpy as np
+    queries, supports = np.asarray(queries, np.float32), np.asarray(supports, np.float32)
+    out = np.full((len(queries), K), len(supports), np.int64)
+    r2 = np.float32(radius) * np.float32(radius)
+    qo = so = 0
+    for nq, ns in zip(q_lens, s_lens):
+        s = supports[so:so + ns]
+        for i in range(qo, qo + nq):
+            d = s - queries[i]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            hit = np.nonzero(d2 < r2)[0][:K]
+            out[i, :len(hit)] = hit + so
+        qo += nq; so += ns
     return out

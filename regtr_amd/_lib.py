@@ -31,8 +31,8 @@ SIGNATURES = {
     'regtr_kdtree_radius_query': (_I, [_P, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _Z, _P, _P, _P, _P, _P]),
     'regtr_cellgrid_ws_bytes': (_Z, [_I, _I]),
     'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
-    'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
-    'regtr_radius_query_self': (_I, [_P, _I, _I, _F, _I, _P, _Z, _P, _P, _P, _P]),
+    'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _P, _P, _P]),
+    'regtr_radius_query_self': (_I, [_P, _I, _I, _F, _I, _I, _P, _Z, _P, _P, _P, _P]),
     'regtr_nearest_in_radius': (_I, [_P, _P, _I, _P, _I, _I, _c.c_double, _F, _P, _Z, _P, _P]),
     'regtr_overlap_avgpool': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),

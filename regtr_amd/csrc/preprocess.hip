@@ -507,7 +507,7 @@ __device__ __forceinline__ void for_each_ranked(uint64_t* list, int n, F&& f)
 
 __global__ void __launch_bounds__(QUERY_WAVES * RG_WAVE)
 k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_off, const int* __restrict__ s_seg_off,
-               int n_clouds, GridView g, float radius, int K, int cap, int* __restrict__ out_idx,
+               int n_clouds, GridView g, float radius, int K, int cap, int by_index, int* __restrict__ out_idx,
                int* __restrict__ out_count, int* __restrict__ out_max_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -572,7 +572,7 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
             // nanoflann.hpp:432-440 : ((0 + dx*dx) + dy*dy) + dz*dz, strict '<' (nanoflann.hpp:249-251)
             float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
             in = d2 < r2;
-            key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(sp.w);
+            key = (by_index ? 0ULL : ((uint64_t)__float_as_uint(d2) << 32)) | (uint32_t)__float_as_int(sp.w);   // order 1: by support index alone
         }
         const unsigned long long bal = __ballot(in);
         if (in) list[n + __popcll(bal & ((1ULL << lane) - 1ULL))] = key;
@@ -622,7 +622,7 @@ k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_of
 constexpr int SELF_CAND = 256;        // staged candidates per cell (cells whose 27-neighbourhood holds more read from global)
 
 __global__ void __launch_bounds__(QUERY_WAVES * RG_WAVE)
-k_radius_query_self(const int* __restrict__ s_seg_off, int n_clouds, GridView g, float radius, int K, int cap,
+k_radius_query_self(const int* __restrict__ s_seg_off, int n_clouds, GridView g, float radius, int K, int cap, int by_index,
                     int* __restrict__ out_idx, int* __restrict__ out_count, int* __restrict__ out_max_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -702,7 +702,7 @@ k_radius_query_self(const int* __restrict__ s_seg_off, int n_clouds, GridView g,
                         const float dx = __fsub_rn(qp.x, sp.x), dy = __fsub_rn(qp.y, sp.y), dz = __fsub_rn(qp.z, sp.z);
                         const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
                         in = d2 < r2;
-                        key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(sp.w);
+                        key = (by_index ? 0ULL : ((uint64_t)__float_as_uint(d2) << 32)) | (uint32_t)__float_as_int(sp.w);   // order 1: by support index alone
                     }
                     const unsigned long long bal = __ballot(in);
                     if (in) list[n + __popcll(bal & ((1ULL << lane) - 1ULL))] = key;
@@ -935,14 +935,16 @@ int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds,
     return RG_OK;
 }
 
-// out_idx [nq_cap * K] int32, rows ascending (d2, support index), padded with Ns_total.
+// out_idx [nq_cap * K] int32, padded with Ns_total; order 0: the K NEAREST supports in the ball, rows ascending (d2, support index) --
+// the reference's CPU Preprocessor (nanoflann, kpconv.py:243-258); order 1: the FIRST K supports in the ball by support index, rows
+// ascending by index -- the reference's PreprocessorGPU (pytorch3d ball_query, kpconv.py:261-288).
 // out_count (optional) [nq_cap]: untruncated number of supports inside the ball.
 // out_max_count (optional): device int, atomically max-ed with the counts (caller zeroes it).
 int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const int* s_seg_off, int ns_cap,
-                       int n_clouds, float radius, int K, const void* grid_ws, size_t ws_bytes, int* out_idx,
+                       int n_clouds, float radius, int K, int order, const void* grid_ws, size_t ws_bytes, int* out_idx,
                        int* out_count, int* out_max_count, void* stream)
 {
-    if (!q_xyz || !q_seg_off || !s_seg_off || !out_idx || n_clouds < 1 || K < 1 || K > 448 || !(radius > 0.f))
+    if (!q_xyz || !q_seg_off || !s_seg_off || !out_idx || n_clouds < 1 || K < 1 || K > 448 || !(radius > 0.f) || (order != 0 && order != 1))
         return RG_ERR_ARG;
     if (ws_bytes < regtr_cellgrid_ws_bytes(ns_cap, n_clouds)) return RG_ERR_WORKSPACE;
     if (nq_cap <= 0) return RG_OK;
@@ -957,17 +959,17 @@ int regtr_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, con
     const size_t lds = (size_t)QUERY_WAVES * (cap + 32) * sizeof(uint64_t);
     const int grid = rg_cdiv(nq_cap, QUERY_WAVES) < 256 * 64 ? rg_xcd_grid(rg_cdiv(nq_cap, QUERY_WAVES)) : 256 * 64;   // query runs inside
     k_radius_query<<<grid, QUERY_WAVES * RG_WAVE, lds, st>>>(
-        q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, out_idx, out_count, out_max_count);
+        q_xyz, q_seg_off, s_seg_off, n_clouds, g, radius, K, cap, order, out_idx, out_count, out_max_count);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
 
 // Self query: the rows of EVERY support point of the grid (queries == supports, e.g. the conv tables of the pyramid) by the
 // cell-centric kernel; out_idx [ns_cap, K] indexed by the ORIGINAL support row.  Same results as regtr_radius_query(s_xyz, ...).
-int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, const void* grid_ws,
+int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, int order, const void* grid_ws,
                             size_t ws_bytes, int* out_idx, int* out_count, int* out_max_count, void* stream)
 {
-    if (!s_seg_off || !out_idx || !grid_ws || n_clouds < 1 || K < 1 || K > 448 || !(radius > 0.f)) return RG_ERR_ARG;
+    if (!s_seg_off || !out_idx || !grid_ws || n_clouds < 1 || K < 1 || K > 448 || !(radius > 0.f) || (order != 0 && order != 1)) return RG_ERR_ARG;
     if (ws_bytes < regtr_cellgrid_ws_bytes(ns_cap, n_clouds)) return RG_ERR_WORKSPACE;
     if (ns_cap <= 0) return RG_OK;
     GridBuffers b = carve_grid((void*)grid_ws, ws_bytes, ns_cap);
@@ -980,7 +982,7 @@ int regtr_radius_query_self(const int* s_seg_off, int ns_cap, int n_clouds, floa
     // waves for 16 slots each of the table's capacity, at most 32 workgroups per CU; the kernel sizes the chunks for the live table
     const long long chunks = ((long long)b.T + 15) / 16;
     const int grid = (int)(rg_cdiv(chunks, QUERY_WAVES) < 256 * 32 ? rg_cdiv(chunks, QUERY_WAVES) : 256 * 32);
-    k_radius_query_self<<<grid, QUERY_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(s_seg_off, n_clouds, g, radius, K, cap, out_idx,
+    k_radius_query_self<<<grid, QUERY_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(s_seg_off, n_clouds, g, radius, K, cap, order, out_idx,
                                                                                      out_count, out_max_count);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

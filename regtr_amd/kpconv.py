@@ -19,6 +19,15 @@ visiting order passed through std::sort (which decides WHICH equidistant support
 min(max_count, K) wide (a full row then has no zero shadow row in max_pool) -- so `kpconv_meta` equals the reference
 `Preprocessor`'s output element for element and the network outputs can be compared with the reference's own at 1e-4
 (tests/test_gpu_model.py).  It costs extra host synchronisations and serial kernels; the default mode stays the fast one.
+
+cfg.kpconv_neighbor_order = 'index' selects the neighbour SETS of the reference's PreprocessorGPU (the class its model actually
+instantiates, regtr.py:29): pytorch3d ball_query keeps the FIRST K supports of a ball in index order (kpconv.py:261-288), where the
+CPU Preprocessor keeps the K nearest.  The two differ only on rows whose ball holds more than neighborhood_limits supports (15 % of
+level-0 rows on 3DMatch).  Same speed as the default; rows come out ascending by support index.  The subsampling is the same in
+both reference paths up to float rounding on voxel boundaries (grid origin = a multiple of dl either way: grid_subsampling.cpp:25-31
+vs floor(p / dl), kpconv.py:232-233) and the row order of MinkowskiEngine's quantisation is unspecified, so it is left as is.
+pytorch3d / MinkowskiEngine cannot be installed here: this mode is pinned to a restatement of ball_query's documented behaviour
+(oracle/regtr_ref.py: ball_query_first_k), not to the libraries themselves.
 """
 from typing import List
 
@@ -66,6 +75,9 @@ class Preprocessor(nn.Module):
         seg = torch.tensor(np.concatenate([[0], np.cumsum(lens0)]).astype(np.int32), device=device)
         # parity mode: the reference CPU ops' implementation-defined row orders and table widths (see module docstring)
         ref_order = bool(cfg.get('kpconv_ref_row_order', False))
+        nb_order = {'nearest': 0, 'index': 1}[cfg.get('kpconv_neighbor_order', 'nearest')]
+        if ref_order and nb_order:
+            raise ValueError('kpconv_ref_row_order reproduces the CPU Preprocessor; kpconv_neighbor_order = index is the GPU one')
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
@@ -89,12 +101,12 @@ class Preprocessor(nn.Module):
             if not ref_order:
                 grid = ops.CellGrid(points, seg, cap, r_normal)
                 if layer_blocks:
-                    conv_i = grid.query(points, seg, cap, K)                             # :349-351
+                    conv_i = grid.query(points, seg, cap, K, order=nb_order)             # :349-351
                 if layer == 0 and level0_event is not None:
                     level0_event.record()
                 if strided:
                     pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)          # :366
-                    pool_i = grid.query(pool_p, pool_seg, cap, K)                        # :376
+                    pool_i = grid.query(pool_p, pool_seg, cap, K, order=nb_order)        # :376
             else:
                 tree = ops.KdTree(points, seg, cap)
                 if layer_blocks:

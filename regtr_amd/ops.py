@@ -47,7 +47,9 @@ class CellGrid:
         check(L.regtr_cellgrid_build(ptr(s_xyz), iptr(s_seg_off), self.n_clouds, self.ns_cap, self.radius, bptr(self.ws),
                                      self.nbytes, stream()), 'regtr_cellgrid_build')
 
-    def query(self, q_xyz, q_seg_off, nq_cap, K, want_count=False):
+    def query(self, q_xyz, q_seg_off, nq_cap, K, want_count=False, order=0):
+        """order 0: the K nearest supports of the ball, rows ascending (d2, index) [reference CPU Preprocessor]; 1: the first K by support
+        index, rows ascending by index [reference PreprocessorGPU / pytorch3d ball_query]."""
         L = _lib.lib()
         idx = torch.empty((max(nq_cap, 1), K), dtype=torch.int32, device=q_xyz.device)
         cnt = mx = None
@@ -56,11 +58,11 @@ class CellGrid:
             mx = torch.zeros(1, dtype=torch.int32, device=q_xyz.device)
         # the grid's own supports: cell-centric kernel (large sets only: one wave per query keeps more of the chip busy on a pair or two)
         if self_query_kernel and q_xyz is self.s_xyz and q_seg_off is self.s_seg_off and self.ns_cap >= SELF_QUERY_MIN_POINTS:
-            check(L.regtr_radius_query_self(iptr(self.s_seg_off), self.ns_cap, self.n_clouds, self.radius, int(K), bptr(self.ws),
-                                            self.nbytes, iptr(idx), iptr(cnt), iptr(mx), stream()), 'regtr_radius_query_self')
+            check(L.regtr_radius_query_self(iptr(self.s_seg_off), self.ns_cap, self.n_clouds, self.radius, int(K), int(order),
+                                            bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt), iptr(mx), stream()), 'regtr_radius_query_self')
         else:
             check(L.regtr_radius_query(ptr(q_xyz), iptr(q_seg_off), int(nq_cap), iptr(self.s_seg_off), self.ns_cap,
-                                       self.n_clouds, self.radius, int(K), bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt),
+                                       self.n_clouds, self.radius, int(K), int(order), bptr(self.ws), self.nbytes, iptr(idx), iptr(cnt),
                                        iptr(mx), stream()), 'regtr_radius_query')
         return (idx, cnt, mx) if want_count else idx
 

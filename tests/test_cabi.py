@@ -39,7 +39,7 @@ def test_argument_errors_return_status_not_crash():
     lib = _lib.lib()
     assert lib.regtr_gemm_f32(None, 4, None, 4, None, 4, 1, 4, 4, None, None, None, 0, 0, None, None, 0, 0.1, None, 0, None) == -2
     assert lib.regtr_gemm_f32_ws_bytes(100000, 128, 64) == 0 and lib.regtr_gemm_f32_ws_bytes(751, 256, 3840) > 0
-    assert lib.regtr_radius_query(None, None, 1, None, 1, 1, 0.1, 40, None, 0, None, None, None, None) == -2
+    assert lib.regtr_radius_query(None, None, 1, None, 1, 1, 0.1, 40, 0, None, 0, None, None, None, None) == -2
     assert lib.regtr_grid_subsample(None, None, 1, 1, 0.1, None, None, None, 0, None) == -2
     with pytest.raises(RuntimeError):
         _lib.check(-3, 'x')

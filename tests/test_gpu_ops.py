@@ -304,6 +304,35 @@ def test_cpp_wrappers_reference_order(case):
         cpp_wrappers.reference_order(prev)
 
 
+def test_radius_first_k_by_index_vs_restatement():
+    """order = 1 (the reference PreprocessorGPU's neighbour sets: first K supports of the ball by index) against the restatement of
+    pytorch3d ball_query, on clouds dense enough that most balls hold more than K supports; per-query and cell-centric kernels."""
+    from oracle import regtr_ref
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    clouds = [synth_cloud(rng, 3000, lattice=0.01), synth_cloud(rng, 2500) + 5.0]
+    s = np.concatenate(clouds).astype(np.float32); lens = np.array([3000, 2500], np.int32)
+    q = np.concatenate([c[::3] for c in clouds]).astype(np.float32); ql = np.array([1000, 834], np.int32)
+    r, K = 0.2, 16
+    seg, qseg = seg_of(lens), seg_of(ql)
+    sd, qd = to_dev(s), to_dev(q)
+    grid = ops.CellGrid(sd, seg, len(s), r)
+    ref_pool = regtr_ref.ball_query_first_k(q, s, ql, lens, r, K)
+    ref_self = regtr_ref.ball_query_first_k(s, s, lens, lens, r, K)
+    assert ((ref_self < len(s)).sum(1) == K).mean() > 0.5                      # truncation really happens
+    got_pool = grid.query(qd, qseg, len(q), K, order=1).cpu().numpy()
+    assert np.array_equal(got_pool, ref_pool)
+    prev = ops.SELF_QUERY_MIN_POINTS
+    try:
+        for min_pts in (1, 1 << 30):                                           # cell-centric kernel, then the per-query kernel
+            ops.SELF_QUERY_MIN_POINTS = min_pts
+            assert np.array_equal(grid.query(sd, seg, len(s), K, order=1).cpu().numpy(), ref_self)
+    finally:
+        ops.SELF_QUERY_MIN_POINTS = prev
+    near = grid.query(qd, qseg, len(q), K, order=0).cpu().numpy()              # the default keeps the K nearest: other sets
+    assert (np.sort(near, 1) != np.sort(got_pool, 1)).any()
+
+
 # ------------------------------------------------------------------------------------------------ encoder kernels
 @pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40),
                                         (16, 64, 40), (48, 32, 40), (20, 12, 33)])      # last three: general LDS-tile gather + flag pass
