@@ -8,7 +8,7 @@ Runs the MI355X-native RegTR inference path over the benchmark's pairs and write
 (3DMatch / 3DLoMatch) or `<log>/pred_transforms.npy` (ModelNet / ModelLoNet) in the reference's formats
 (models/generic_reg_model.py:194-195, 260-281), which the reference's evaluation scripts read unchanged.
 Inference only: no loss, no tensorboard.  Extra flags: --batch (pairs per forward), --data_root, --synthetic N
-(N deterministic synthetic pairs instead of the dataset files), --max_pairs, --benchmark_dir (gt.log / gt.info folder: the
+(N deterministic synthetic pairs instead of the dataset files), --max_pairs, --neighbor_order (nearest | index: which reference preprocessor's neighbour rule), --benchmark_dir (gt.log / gt.info folder: the
 Predator registration-recall table of benchmark/benchmark_predator.py is then printed, computed in process).
 """
 import argparse
@@ -39,6 +39,9 @@ parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.r
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
 parser.add_argument('--max_pairs', type=int, default=None)
+parser.add_argument('--neighbor_order', choices=('nearest', 'index'), default=None,
+                    help='neighbour selection rule: nearest = the reference CPU Preprocessor (default), index = its PreprocessorGPU '
+                         '(pytorch3d ball_query: first K supports of a ball by index); overrides cfg.kpconv_neighbor_order')
 parser.add_argument('--benchmark_dir', type=str, default=os.path.join('datasets', '3dmatch', 'benchmarks'),
                     help='folder with <benchmark>/<scene>/gt.log, gt.info for the registration-recall table')
 
@@ -89,6 +92,8 @@ def main():
     from regtr_amd import RegTR, load_config
     from regtr_amd import harness
     cfg = load_config(opt.config)
+    if opt.neighbor_order:
+        cfg.update({'kpconv_neighbor_order': opt.neighbor_order})
     if cfg.dataset == '3dmatch':
         assert opt.benchmark in ['3DMatch', '3DLoMatch'], "Benchmark for 3dmatch dataset must be one of ['3DMatch', '3DLoMatch']"
         cfg.benchmark = opt.benchmark
