@@ -112,3 +112,23 @@ def test_compute_overlaps_restatement_vs_reference_golden():
                                       'kpconv_meta': meta})
     for p in range(4):
         assert np.allclose(pyr[f'pyr_{p}'].numpy(), g[f'pyr_{p}'], rtol=0, atol=1e-7, equal_nan=True), p
+
+
+def test_ball_query_first_k_properties():
+    """The restatement of the reference PreprocessorGPU's neighbour rule (pytorch3d ball_query, kpconv.py:261-288): every row holds
+    the smallest K indices of the ball, ascending, same cloud only, padded with the support count."""
+    from oracle import regtr_ref
+    rng = np.random.default_rng(3)
+    s = rng.uniform(0, 1, (400, 3)).astype(np.float32); s[200:] += 3.0
+    q = s[::2].copy()
+    lens, ql = np.array([200, 200]), np.array([100, 100])
+    r, K = 0.35, 8
+    t = regtr_ref.ball_query_first_k(q, s, ql, lens, r, K)
+    assert t.shape == (200, K)
+    for i in range(len(q)):
+        lo, hi = (0, 200) if i < 100 else (200, 400)
+        d2 = ((s[lo:hi] - q[i]) ** 2).sum(1)
+        ball = np.nonzero(d2 < np.float32(r) ** 2)[0] + lo
+        want = list(ball[:K]) + [len(s)] * (K - min(K, len(ball)))
+        assert list(t[i]) == want
+    assert (np.diff(np.where(t < len(s), t, len(s) + np.arange(K)), axis=1) > 0).all()      # ascending inside a row
