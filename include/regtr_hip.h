@@ -149,6 +149,15 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, int ld_wf, float* num,
                         void* stream);
 
+/* KPConv.forward (kpconv_blocks.py:269-414) in ONE launch for the level-0 shape -- 32 -> 32 channels, 15 kernel points, rows of at
+ * most 40 neighbours (regtr_kpconv_fused_supported): gather, kernel-point correlation, contraction with W [480,32] and the division
+ * by the neighbour count, the weighted features staying in LDS (they are 4.6 GB per convolution of a 64-pair forward otherwise).
+ * x [ns,32]: FINAL features; s_xyzf [ns,4]: (x, y, z, positivity flag) records (regtr_instnorm_apply's row_xyz form);
+ * planes = regtr_gemm_split_weights(W as [480,32], transposed = 1).  out [nq,32]. */
+int regtr_kpconv_fused_supported(int Cin, int Cout, int KP, int H);
+int regtr_kpconv_fused(const float* q_xyz, int nq, int ns, const int* nbr, int H, const float* x, const float* s_xyzf,
+                       const float* kernel_points, int KP, float extent, const void* planes, float* out, void* stream);
+
 /* out[q,:] = max over the first H columns of row q of nbr (row stride ld_nbr >= H) of x[nbr[q,h],:], the shadow index
  * ns standing for a zero row (kpconv_blocks.py:127-143).  H < ld_nbr serves the reference's CPU tables, whose width is
  * min(max in-ball count, neighborhood_limit) (kpconv.py:255-258): a full row then holds no shadow and its maximum may be negative. */

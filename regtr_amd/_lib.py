@@ -54,6 +54,8 @@ SIGNATURES = {
     'regtr_gemm_x3_tile_rows': (_I, [_I, _I, _I]),
     'regtr_gemm_stream_supported': (_I, [_I, _I, _I]),
     'regtr_gemm_stream_tile_rows': (_I, []),
+    'regtr_kpconv_fused_supported': (_I, [_I, _I, _I, _I]),
+    'regtr_kpconv_fused': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_block_tail_supported': (_I, [_I, _I, _I, _I]),
     'regtr_block_tail_ws_bytes': (_Z, [_I, _I, _I, _I, _I]),
     'regtr_block_tail': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P, _P]),

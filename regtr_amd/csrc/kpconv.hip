@@ -436,6 +436,197 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Gather FUSED with the kernel-point contraction, for the level-0 shape (Cin = Cout = 32, 15 kernel points): the weighted features
+// never go to HBM (4.6 GB written and 4.6 GB read back per level-0 convolution of a 64-pair forward otherwise).
+//   * one workgroup = 16 waves; each wave gathers one query per ROUND exactly as k_kpconv_gather_mfma<J, 2, true> does (final
+//     features, packed support records) and leaves its WF[15][32] tile in LDS -- 16 queries per round = the M of a 16x16x16 MFMA;
+//   * the three bf16 planes of W[480][32] (92 KB, rows padded to 488 for the banks) are resident in LDS for the workgroup's life;
+//   * barrier; the 16 waves share the [16 x 480] x [480 x 32] product: wave (kg, nt) takes 3-4 of the 30 k-steps of one 16-column
+//     half (A fragment = 16 bytes of a query's WF row, split exactly into three bf16 planes; six MFMAs per step: float32-grade like
+//     gemm_x3.hip), partial 16 x 16 tiles go to LDS; barrier; 512 threads add the 8 partials of an output in fixed order
+//     (deterministic), divide by the neighbour count (kpconv_blocks.py:411) and store.
+// The price is two workgroup barriers per query round (measured on the plain gather: +22 %); what it buys is the whole contraction
+// launch and the WF stores.
+typedef short rg_s4 __attribute__((ext_vector_type(4)));
+constexpr int FU_WAVES = 16, FU_QPW = 16, FU_K = 480, FU_WROW = 488, FU_N = 32;
+
+struct FusedArgs {
+    const float* q_xyz; const int* nbr; const float* x; const float* s_xyzf; const float* kp; const uint16_t* Wt;
+    float* out;
+    size_t plane;                 // elements per weight plane in global memory (Npad * Kp)
+    int nq, ns, H, KP, Kp;
+    float extent;
+};
+
+__device__ __forceinline__ unsigned fu_pack(float a, float b)
+{
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 v;
+    v.x = (__bf16)a; v.y = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void fu_split2(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2)
+{
+    p0 = fu_pack(a, b);
+    const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = fu_pack(ra, rb);
+    p2 = fu_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
+}
+
+template <int J>
+__global__ void __launch_bounds__(FU_WAVES * RG_WAVE) k_kpconv_fused(FusedArgs g)
+{
+    constexpr int HP = 4 * J, Cin = 32;
+    extern __shared__ __align__(16) unsigned char fsm[];
+    uint16_t* Wl = (uint16_t*)fsm;                                            // [3][32][FU_WROW] bf16
+    float* wf_s = (float*)(fsm + (size_t)3 * FU_N * FU_WROW * 2);             // [16 queries][480]
+    float* part_s = wf_s + FU_WAVES * FU_K;                                   // [8 k-groups][2 halves][16 x 16]
+    float4* nb_all = (float4*)(part_s + 8 * 2 * 256);                         // [16 waves][HP]
+    float* num_s = (float*)(nb_all + FU_WAVES * HP);                          // [2][16]
+    int* qidx_s = (int*)(num_s + 2 * FU_WAVES);                               // [2][16]
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = rg_lane();
+    const int k = lane & 15, hh = lane >> 4;
+    const int H = g.H, ns = g.ns, nq = g.nq;
+    float4* nb_s = nb_all + wave * HP;
+    const bool kvalid = k < g.KP;
+    const int kc = kvalid ? k : 0;
+    const float kx = kvalid ? g.kp[3 * kc] : 1e30f, ky = g.kp[3 * kc + 1], kz = g.kp[3 * kc + 2];
+    const float inv_extent = 1.0f / g.extent;
+    constexpr unsigned row_bytes = Cin * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = rg_rsrc(g.x, (unsigned)ns * row_bytes);
+    const __amdgpu_buffer_rsrc_t xyzf_rs = rg_rsrc(g.s_xyzf, (unsigned)ns * 16u);
+    const unsigned lane_off = (unsigned)(2 * k) * 4u;
+
+    // weight planes -> LDS (16-byte chunks; 60 per 480-bf16 row)
+    for (int idx = t; idx < 3 * FU_N * 60; idx += FU_WAVES * RG_WAVE) {
+        const int p = idx / (FU_N * 60), rem = idx - p * (FU_N * 60), n = rem / 60, c = rem - n * 60;
+        *(uint4*)(Wl + (size_t)(p * FU_N + n) * FU_WROW + c * 8) = *(const uint4*)(g.Wt + (size_t)p * g.plane + (size_t)n * g.Kp + c * 8);
+    }
+
+    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * FU_WAVES + wave) * FU_QPW;
+    const int hl = lane < H ? lane : H - 1;
+    auto load_idx = [&](int q) -> int {
+        const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + hl];
+        return (q < nq && lane < H) ? v : ns;
+    };
+    struct Nb { float rx, ry, rz, f; };
+    auto load_nb = [&](int q, int idx) -> Nb {
+        const bool real = idx < ns;
+        const rg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xyzf_rs, real ? (unsigned)idx * 16u : RG_OOB, 0, 0);
+        const unsigned qc = (unsigned)(q < nq ? q : nq - 1);
+        const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
+        Nb n;
+        n.rx = (real ? __uint_as_float(r.x) : 1e6f) - qx; n.ry = (real ? __uint_as_float(r.y) : 1e6f) - qy;
+        n.rz = (real ? __uint_as_float(r.z) : 1e6f) - qz; n.f = real ? __uint_as_float(r.w) : 0.f;
+        return n;
+    };
+    int idx_cur = load_idx(qbase);
+    Nb nb_cur = load_nb(qbase, idx_cur);
+    int idx_nxt = load_idx(qbase + 1);
+    // stage-2 role of this wave: 16-column half nt, k-steps [ks0, ks0 + nks) of the 30
+    const int nt = wave & 1, kg = wave >> 1;
+    const int ks0 = kg < 6 ? 4 * kg : 24 + 3 * (kg - 6), nks = kg < 6 ? 4 : 3;
+    int par = 0;
+#pragma unroll 1
+    for (int qq = 0; qq < FU_QPW; qq++) {                      // every wave runs every round (barriers inside); q >= nq: a zero tile
+        const int q = qbase + qq;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < HP) {
+            const unsigned ro = idx_cur < ns ? (unsigned)idx_cur * row_bytes : RG_OOB;
+            nb_s[lane] = make_float4(nb_cur.rx, nb_cur.ry, nb_cur.rz, __uint_as_float(ro));
+        }
+        __builtin_amdgcn_wave_barrier();
+        float w[J];
+        unsigned row[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const float4 nb = nb_s[4 * j + hh];
+            const float dx = nb.x - kx, dy = nb.y - ky, dz = nb.z - kz;
+            float d2;
+            {
+#pragma clang fp contract(off)
+                d2 = (dx * dx + dy * dy) + dz * dz;                                   // kpconv_blocks.py:326-329
+            }
+            w[j] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);         // :368
+            row[j] = __float_as_uint(nb.w) + lane_off;
+        }
+        float2 xv[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) xv[j] = rg_buf_load<2>(x_rs, row[j]);
+        const float f_cur = nb_cur.f;
+        Nb nb_nxt = load_nb(q + 1, idx_nxt);
+        const int idx_nn = load_idx(q + 2);
+        floatx4 acc0 = floatx4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], xv[j].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], xv[j].y, acc1, 0, 0, 0);
+        }
+        // WF tile -> LDS: lane holds WF[kk = 4 hh + r][c = 2 k, 2 k + 1]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int kk = 4 * hh + r;
+            if (kk < 15) *(float2*)(wf_s + wave * FU_K + kk * Cin + 2 * k) = make_float2(acc0[r], acc1[r]);
+        }
+        const float cnt = (float)__builtin_popcountll(__ballot(f_cur > 0.f));
+        if (lane == 0) { num_s[par * FU_WAVES + wave] = fmaxf(cnt, 1.f); qidx_s[par * FU_WAVES + wave] = q < nq ? q : -1; }
+        idx_cur = idx_nxt; nb_cur = nb_nxt; idx_nxt = idx_nn;
+        __syncthreads();                                                       // the 16 tiles (and, first round, the weights) are in LDS
+        // ---- stage 2: [16 queries x 480] x [480 x 32], this wave's share
+        // all fragments of the wave's (up to four) k-steps first, then three independent MFMA chains: between two workgroup barriers
+        // the latency of this stage is what every wave of the workgroup waits for
+        float4 av[4];
+        uint2 bv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int ks = ks0 + (i < nks ? i : 0);
+            av[i] = *(const float4*)(wf_s + k * FU_K + 16 * ks + 4 * hh);     // query slot k (= lane & 15), 4 consecutive k-indices
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+                bv[i][p] = *(const uint2*)(Wl + (size_t)(p * FU_N + 16 * nt + k) * FU_WROW + 16 * ks + 4 * hh);
+        }
+        floatx4 o0 = floatx4{0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < nks) {                                                     // wave-uniform
+                unsigned a0[3], a1[3];
+                fu_split2(av[i].x, av[i].y, a0[0], a0[1], a0[2]);
+                fu_split2(av[i].z, av[i].w, a1[0], a1[1], a1[2]);
+                rg_s4 fa[3], fb[3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) {
+                    fa[p] = __builtin_bit_cast(rg_s4, make_uint2(a0[p], a1[p]));
+                    fb[p] = __builtin_bit_cast(rg_s4, bv[i][p]);
+                }
+                o2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[2], fb[0], o2, 0, 0, 0);      // the 2^-16 terms
+                o2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[1], fb[1], o2, 0, 0, 0);
+                o2 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[0], fb[2], o2, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[1], fb[0], o1, 0, 0, 0);      // the 2^-8 terms
+                o1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[0], fb[1], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(fa[0], fb[0], o0, 0, 0, 0);
+            }
+        }
+        floatx4 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (o2[i] + o1[i]) + o0[i];            // smallest first
+        // D: lane holds out[query slot 4 hh + i][column 16 nt + k]
+#pragma unroll
+        for (int i = 0; i < 4; i++) part_s[(kg * 2 + nt) * 256 + (4 * hh + i) * 16 + k] = o[i];
+        __syncthreads();
+        if (t < 512) {
+            const int qs = t >> 5, col = t & 31, h2 = col >> 4, c = col & 15;
+            float sum = part_s[h2 * 256 + qs * 16 + c];
+#pragma unroll
+            for (int g2 = 1; g2 < 8; g2++) sum += part_s[(g2 * 2 + h2) * 256 + qs * 16 + c];
+            const int qi = qidx_s[par * FU_WAVES + qs];
+            if (qi >= 0) g.out[(size_t)qi * FU_N + col] = sum / num_s[par * FU_WAVES + qs];
+        }
+        par ^= 1;
+    }
+}
+
 // Cin == 1 (first encoder block, features = ones): no channel dimension to spread over lanes, so lanes are
 // (query, kernel point) pairs: 4 queries x 16 kernel points per wave, each lane walks its query's neighbours once and
 // accumulates influence x feature directly -- no influence tile in LDS, 6 floats of LDS per neighbour instead of 22.
@@ -588,6 +779,31 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     if (LQ == 16) k_kpconv_gather<16><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else if (LQ == 32) k_kpconv_gather<32><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
     else k_kpconv_gather<64><<<grid, GATHER_WAVES * RG_WAVE, lds, st>>>(g);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// 1 when regtr_kpconv_fused serves the convolution: 32 -> 32 channels, 15 kernel points, rows of at most 40 neighbours
+int regtr_kpconv_fused_supported(int Cin, int Cout, int KP, int H) { return (Cin == 32 && Cout == 32 && KP == 15 && H >= 1 && H <= 40) ? 1 : 0; }
+
+// KPConv.forward in ONE launch for the level-0 shape: out[nq, 32] = (gather + kernel-point correlation) x W / neighbour count
+// (kpconv_blocks.py:269-414).  x [ns,32] final features, s_xyzf [ns,4] = (x, y, z, positivity flag) records (regtr_instnorm_apply),
+// planes = regtr_gemm_split_weights(W viewed as [480, 32], transposed = 1).
+int regtr_kpconv_fused(const float* q_xyz, int nq, int ns, const int* nbr, int H, const float* x, const float* s_xyzf,
+                       const float* kernel_points, int KP, float extent, const void* planes, float* out, void* stream)
+{
+    if (!q_xyz || !nbr || !x || !s_xyzf || !kernel_points || !planes || !out || nq < 0 || ns < 1 || !(extent > 0.f)) return RG_ERR_ARG;
+    if (!regtr_kpconv_fused_supported(32, 32, KP, H) || (long long)ns * 32 >= (1LL << 29)) return RG_ERR_ARG;
+    if (((uintptr_t)x | (uintptr_t)s_xyzf | (uintptr_t)planes | (uintptr_t)out) % 16) return RG_ERR_ARG;
+    if (nq == 0) return RG_OK;
+    const int Kp = FU_K, Npad = 128;                              // regtr_gemm_split_weights(N = 32, K = 480): Kp = 480, Npad = 128
+    FusedArgs g{q_xyz, nbr, x, s_xyzf, kernel_points, (const uint16_t*)planes, out, (size_t)Npad * Kp, nq, ns, H, KP, Kp, extent};
+    constexpr int J = 10, HP = 4 * J;
+    const size_t lds = (size_t)3 * FU_N * FU_WROW * 2 + (size_t)FU_WAVES * FU_K * 4 + 8 * 2 * 256 * 4 + (size_t)FU_WAVES * HP * 16 + 2 * FU_WAVES * 8;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)k_kpconv_fused<J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const int grid = rg_xcd_grid(rg_cdiv(nq, FU_WAVES * FU_QPW));
+    k_kpconv_fused<J><<<grid, FU_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(g);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -118,7 +118,9 @@ class SplitWeight:
             self.K, self.N = w.shape
             self.kn = w
         self.planes = None
-        if L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K):
+        # (480 x 32: the level-0 KPConv weights, for regtr_kpconv_fused)
+        if (L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K)
+                or (self.N == 32 and self.K == 480)):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
             check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
                                              stream()), 'regtr_gemm_split_weights')
@@ -283,6 +285,9 @@ def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_o
 
 STREAM_MIN_ROWS = 131072     # below this a forward is launch-bound (a pair or two): the tiled kernels and separate passes are as fast
 use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
+# level-0 gather + contraction in one launch (regtr_kpconv_fused): correct and tested, but 3.35 ms against 3.08 ms for the two
+# kernels at level 0 of a 64-pair forward (two workgroup barriers per query round) -- off until it is pipelined
+use_fused_kpconv = os.environ.get('REGTR_FUSED_KPCONV', '0') != '0'
 use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
 PRENORM_MIN_ROWS = 65536        # below this a forward is launch-bound: the extra normalise pass costs more than the gather saves
 prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
@@ -349,6 +354,23 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         flag = torch.empty(ns, dtype=torch.float32, device=dev)
         check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), iptr(s_seg_off) if x_stats is not None else None, n_seg,
                                       slope, ptr(flag), stream()), 'regtr_rowsum_positive')
+    # level-0 shape with packed records: gather + contraction + / count in one launch, the weighted features never leave the chip
+    if (use_fused_kpconv and xyzf is not None and Cin > 1 and isinstance(w_flat, SplitWeight) and w_flat.planes is not None
+            and nq >= STREAM_MIN_ROWS and L.regtr_kpconv_fused_supported(Cin, w_flat.N, KP, H)
+            and x.data_ptr() % 16 == 0 and ns * Cin < (1 << 29)):
+        out = torch.empty((nq, w_flat.N), dtype=torch.float32, device=dev)
+        rec = gather_records
+        if rec is not None:
+            e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
+            e0.record()
+        check(L.regtr_kpconv_fused(ptr(q_xyz), nq, ns, iptr(nbr), H, ptr(x), ptr(xyzf), ptr(kernel_points), KP, float(extent),
+                                   bptr(w_flat.planes), ptr(out), stream()), 'regtr_kpconv_fused')
+        if rec is not None:
+            e1.record()
+            rec.append((e0, e1, e1, nq, H, Cin, w_flat.N))
+        if want_stats is None:
+            return out
+        return out, instnorm_stats(out, want_stats[0], want_stats[1])
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
     rec = gather_records

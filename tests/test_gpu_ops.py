@@ -413,6 +413,43 @@ def test_fused_instnorm_paths_vs_oracle():
     assert (out2.cpu() - ref2).abs().max() < 3e-5 * max(1.0, ref2.abs().max().item())
 
 
+@pytest.mark.parametrize('nq_take', [1, 3])
+def test_kpconv_fused_vs_two_kernel_path(nq_take):
+    """regtr_kpconv_fused (level-0 shape: 32 -> 32 channels, weighted features kept in LDS) against gather + contraction, same inputs:
+    float32 rounding only.  Query counts that are not multiples of the workgroup's 256 (surplus waves run zero tiles)."""
+    from oracle import native
+    from regtr_amd.kernel_points import K015_CENTER
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    clouds = [synth_cloud(rng, 3000), synth_cloud(rng, 2101) + 6.0]
+    s = np.concatenate(clouds).astype(np.float32); lens = np.array([3000, 2101], np.int32)
+    q = s[::nq_take].copy(); ql = np.array([len(range(0, 3000, nq_take)), len(s[::nq_take]) - len(range(0, 3000, nq_take))], np.int32)
+    if nq_take > 1:      # strided-style: queries are a subset; keep clouds separate
+        q = np.concatenate([clouds[0][::nq_take], clouds[1][::nq_take]]).astype(np.float32)
+        ql = np.array([len(clouds[0][::nq_take]), len(clouds[1][::nq_take])], np.int32)
+    r = 0.12
+    idx, _, _ = native.radius_neighbors(q, s, ql, lens, r, 40)
+    x = rng.standard_normal((len(s), 32)).astype(np.float32)
+    x[rng.random(len(s)) < 0.3] *= -1.0
+    w = (rng.standard_normal((15 * 32, 32)) / 20).astype(np.float32)
+    kp = (K015_CENTER * r).astype(np.float32)
+    xd = to_dev(x)
+    xyzf = torch.cat((to_dev(s), (xd.sum(1, keepdim=True) > 0).float()), 1).contiguous()
+    sw = ops.SplitWeight(to_dev(w), 'kn')
+    assert sw.planes is not None
+    args = (to_dev(q), to_dev(s), to_dev(idx), xd, sw, to_dev(kp), r * 0.8)
+    prev = (ops.STREAM_MIN_ROWS, ops.use_fused_kpconv)
+    try:
+        ops.STREAM_MIN_ROWS = 1
+        ops.use_fused_kpconv = True
+        fused = ops.kpconv(*args, xyzf=xyzf)
+        ops.use_fused_kpconv = False
+        plain = ops.kpconv(*args, xyzf=xyzf)
+    finally:
+        ops.STREAM_MIN_ROWS, ops.use_fused_kpconv = prev
+    assert (fused - plain).abs().max().item() < 3e-6 * max(1.0, plain.abs().max().item())
+
+
 def test_maxpool_instnorm_vs_oracle():
     from oracle import native, regtr_ref
     ops = _ops()
