@@ -209,25 +209,141 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0, cfg_name='3dmatch'):
                       f'median s/pair {med:.3f}{split}'}
 
 
+def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mode=False, first_id=None, distinct=None):
+    """The benchmarked model and batch, exactly as the timed loop uses them (tests/test_gpu_bench_batch.py builds the same objects):
+    conf/<config>.yaml architecture with torch.manual_seed(0) random-init weights, `n_pairs` deterministic synthetic pairs
+    (ids rank * 100003 + i, or first_id + i) resident on `dev`.  config 'lomatch' = the 3dmatch pipeline on 10-30 %-overlap pairs.
+    distinct: generate only that many different pairs and cycle through them (setup time; nothing is cached between pairs).
+    -> (cfg, model, pairs [(src, tgt) numpy], batch {'src_xyz': [...], 'tgt_xyz': [...]})"""
+    from regtr_amd import RegTR, load_config
+    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{"3dmatch" if config == "lomatch" else config}.yaml'))
+    cfg.update({'compute_dtype': dtype})
+    if parity_mode:
+        cfg.update({'kpconv_ref_row_order': True})
+    torch.manual_seed(0); np.random.seed(0)
+    model = RegTR(cfg).to(dev).eval()
+    base = rank * 100003 if first_id is None else first_id
+    n_gen = n_pairs if not distinct else min(n_pairs, distinct)
+    if config == 'modelnet':
+        gen = [synth_modelnet_pair(base + i) for i in range(n_gen)]
+    else:
+        gen = [synth_pair(base + i, points, shuffle, overlap='lomatch' if config == 'lomatch' else None) for i in range(n_gen)]
+    pairs = [gen[i % n_gen] for i in range(n_pairs)]
+    dev_pairs = [(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)) for s, t in gen]
+    batch = {'src_xyz': [dev_pairs[i % n_gen][0] for i in range(n_pairs)], 'tgt_xyz': [dev_pairs[i % n_gen][1] for i in range(n_pairs)]}
+    return cfg, model, pairs, batch
+
+
+PARITY_TOL = 1e-4      # BASELINE.json north_star: "predicted correspondences and R|t within 1e-4 abs"
+
+
+def parity_check(cfg, model, pairs, out, which, parity_mode=False):
+    """BASELINE.json's metric is "pairs/sec ...; pose err vs ref": the outputs of the LAST TIMED STEP (`out`, the product's dict for
+    the whole batch) for the pairs `which`, against the CPU oracle run on each of those pairs alone with the same weights --
+    oracle/regtr_ref.py (pinned to the real reference module, tests/test_oracle.py) over the canonical tables built from the
+    unmodified reference C++'s neighbour sets (oracle/canonical.py); in --parity-mode over the reference C++'s own orders.
+    Quantities: /root/reference/src/models/regtr.py:185-235 (pose, correspondences, overlap logits), utils/se3_torch.py:108-154.
+    The oracle is the CHECKER here (outside the timed region), never the thing measured."""
+    from oracle import canonical, native, regtr_ref
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.set_num_threads(max(1, min(usable_cores(), 16)))
+    worst = {'pose_max_abs': 0.0, 'corr_max_abs': 0.0, 'overlap_logit_max_abs': 0.0}
+    kp_exact = True
+    t0 = time.perf_counter()
+    for b in which:
+        s, t = pairs[b]
+        with torch.no_grad():
+            if parity_mode:
+                ref = regtr_ref.regtr_forward(sd, cfg, [s], [t], use_ref_cpp=True)
+            else:
+                ref = regtr_ref.regtr_forward(sd, cfg, [s], [t], meta=canonical.canonical_meta([s, t], cfg))
+        kp_exact = kp_exact and torch.equal(out['src_kp'][b].cpu(), ref['src_kp'][0]) and torch.equal(out['tgt_kp'][b].cpu(), ref['tgt_kp'][0])
+        if not kp_exact:
+            break
+        worst['pose_max_abs'] = max(worst['pose_max_abs'], float((out['pose'][:, b].cpu() - ref['pose'][:, 0]).abs().max()))
+        for k in ('src_kp_warped', 'tgt_kp_warped'):
+            worst['corr_max_abs'] = max(worst['corr_max_abs'], float((out[k][b].cpu() - ref[k][0]).abs().max()))
+        for k in ('src_overlap', 'tgt_overlap'):
+            worst['overlap_logit_max_abs'] = max(worst['overlap_logit_max_abs'], float((out[k][b].cpu() - ref[k][0]).abs().max()))
+    ok = kp_exact and max(worst['pose_max_abs'], worst['corr_max_abs']) < PARITY_TOL
+    return dict(worst, pairs_checked=len(which), pair_slots=list(which), keypoints_bit_exact=kp_exact, tol=PARITY_TOL, ok=bool(ok),
+                vs=('CPU oracle (oracle/regtr_ref.py, pinned to the reference module) per pair, ' +
+                    ('reference row / tie orders (oracle/_ref), product in parity mode' if parity_mode else
+                     'canonical tables from ' + ('the unmodified reference C++ neighbour sets (oracle/_ref)' if native.have_ref() else 'the C++ restatement'))),
+                what='outputs of the last timed step', seconds=round(time.perf_counter() - t0, 2))
+
+
+def plan_pairs(args, rank, world, device):
+    """Which pairs this rank runs and how they are cut into forwards.  Weak scaling (default): `--pairs` pairs per rank and step, ids
+    rank * pairs + i.  --config lomatch (configs[3], strong scaling): a fixed set of --total-pairs pairs, pair i -> rank i % world
+    (regtr_amd/distributed.py: shard_pairs), `--pairs` per forward with a ragged last forward.
+    -> (lomatch, per_fwd, pair_ids (n_local,) i32 on `device`, chunks [(lo, hi)], pairs_per_step over all ranks)"""
+    from regtr_amd.distributed import shard_pairs
+    lomatch = args.config == 'lomatch'
+    per_fwd = args.pairs if args.pairs else (256 if args.config == 'modelnet' else 64)
+    args.pairs = per_fwd
+    if lomatch:
+        mine = shard_pairs(args.total_pairs, rank, world)
+        pair_ids = torch.tensor(mine, device=device, dtype=torch.int32)
+    else:
+        pair_ids = torch.arange(per_fwd, device=device, dtype=torch.int32) + rank * per_fwd
+    n_local = int(pair_ids.numel())
+    chunks = [(lo, min(lo + per_fwd, n_local)) for lo in range(0, n_local, per_fwd)]
+    return lomatch, per_fwd, pair_ids, chunks, (args.total_pairs if lomatch else per_fwd * world)
+
+
+def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
+    """W untimed + exactly K timed steps between barrier + device synchronisation on both sides, MAX over ranks.  The poses reach every
+    rank through ONE all_gather (regtr_amd/distributed.py) -- per pass over the set for lomatch, once at the end of the timed region
+    otherwise.  step() -> (poses (n_local, 3, 4) of this rank's pairs, anything).  -> (elapsed s, all poses, all ids, last step's extra)"""
+    from regtr_amd.distributed import gather_poses
+    gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    poses = extra = gathered = None
+    for _ in range(args.steps):
+        poses, extra = step()
+        if lomatch:
+            gathered = gather(poses)
+    if not lomatch:
+        gathered = gather(poses)
+    sync()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, gathered[0], gathered[1], extra
+
+
+def count_ranks(all_ids, lomatch, per_fwd, world):
+    """Ranks whose poses arrived through the gather (the owner of pair id i is i % world in a sharded set, i // pairs otherwise)."""
+    owner = torch.remainder(all_ids, world) if lomatch else torch.div(all_ids, per_fwd, rounding_mode='floor')
+    return int(torch.unique(owner).numel())
+
+
 def run_stub(args, rank, world, dist):
     """tests/test_bench_entry.py: the launch / sharding / gather / reporting logic of this script on CPU (gloo) with a
     stand-in for the forward -- no kernels, no claims; prints the same JSON shape with metric 'stub'."""
-    from regtr_amd.distributed import gather_poses
-    pair_ids = torch.arange(args.pairs, dtype=torch.int32) + rank * args.pairs
-    eye = torch.eye(3, 4).reshape(1, 12).repeat(args.pairs, 1)
-    if dist: dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        poses = eye + pair_ids[:, None].float()
-    all_poses, all_ids = gather_poses(poses, pair_ids) if dist else (poses, pair_ids)
-    if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
-    ranks_seen = int(torch.unique(torch.div(all_ids, args.pairs, rounding_mode='floor')).numel())
-    assert all_poses.shape[0] == args.pairs * world and ranks_seen == world
+    cpu = torch.device('cpu')
+    lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, cpu)
+    eye = torch.eye(3, 4).reshape(1, 3, 4)
+
+    def step():
+        return torch.cat([eye + pair_ids[lo:hi, None, None].float() for lo, hi in chunks]), None
+    elapsed, all_poses, all_ids, _ = timed_passes(args, dist, lomatch, pair_ids, step, lambda: None, cpu)
+    ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)
+    assert all_poses.shape[0] == pairs_per_step and ranks_seen == world
     assert torch.equal(all_poses[:, 0], 1 + all_ids.float())
+    assert torch.equal(all_ids, torch.sort(all_ids)[0]) and (not lomatch or torch.equal(all_ids.long(), torch.arange(args.total_pairs)))
     if rank == 0:
-        print(json.dumps({'metric': 'stub', 'value': world * args.steps * args.pairs / max(elapsed, 1e-9), 'unit': 'pairs/s',
-                          'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup}))
+        print(json.dumps({'metric': 'stub', 'value': args.steps * pairs_per_step / max(elapsed, 1e-9), 'unit': 'pairs/s',
+                          'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'pairs_per_step': pairs_per_step,
+                          'forwards_per_step_rank0': len(chunks), 'scaling': 'strong' if lomatch else 'weak'}))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -238,8 +354,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', choices=['3dmatch', 'modelnet'], default='3dmatch',
-                    help='3dmatch = BASELINE configs[2] (the headline metric); modelnet = configs[1] (ModelNet-size pairs, bf16 cross-encoder)')
+    ap.add_argument('--config', choices=['3dmatch', 'modelnet', 'lomatch'], default='3dmatch',
+                    help='3dmatch = BASELINE configs[2] (the headline metric); modelnet = configs[1] (ModelNet-size pairs, bf16 cross-encoder); '
+                         'lomatch = configs[3]: --total-pairs 10-30 %%-overlap pairs sharded over the ranks (strong scaling), a step = one pass over the set')
+    ap.add_argument('--total-pairs', type=int, default=1781, help='lomatch: size of the pair set (3DLoMatch test list: 1781)')
+    ap.add_argument('--distinct-pairs', type=int, default=128, help='lomatch: different synthetic pairs generated per rank (cycled; set-up time only)')
+    ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
+    ap.add_argument('--parity-pairs', type=int, default=2, help='pairs of the last timed step checked against the CPU oracle (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
     ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
@@ -253,10 +374,12 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_only:
         from regtr_amd.config import load_config
-        cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
-        gen = (lambda i: synth_modelnet_pair(i)) if args.config == 'modelnet' else (lambda i: synth_pair(i, args.points, args.shuffle))
-        print(json.dumps({'cpu_baseline': cpu_baseline(cfg, [gen(i) for i in range(6 if args.config == '3dmatch' else 24)],
-                                                       cfg_name=args.config), 'config': args.config}))
+        arch = '3dmatch' if args.config == 'lomatch' else args.config
+        cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{arch}.yaml'))
+        gen = ((lambda i: synth_modelnet_pair(i)) if args.config == 'modelnet' else
+               (lambda i: synth_pair(i, args.points, args.shuffle, overlap='lomatch' if args.config == 'lomatch' else None)))
+        print(json.dumps({'cpu_baseline': cpu_baseline(cfg, [gen(i) for i in range(24 if args.config == 'modelnet' else 6)],
+                                                       cfg_name=arch), 'config': args.config}))
         return
 
     if args.gpus < 1:
@@ -292,49 +415,25 @@ def main():
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
-    from regtr_amd import RegTR, load_config
-    from regtr_amd.distributed import gather_poses
-    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
     dtype = args.dtype or ('bf16' if args.config == 'modelnet' else 'fp32')
-    cfg.update({'compute_dtype': dtype})
-    torch.manual_seed(0); np.random.seed(0)
-    model = RegTR(cfg).to(dev).eval()
-
-    n_pairs = args.pairs if args.pairs else (256 if args.config == 'modelnet' else 64)
-    args.pairs = n_pairs
-    if args.config == 'modelnet':
-        pairs = [synth_modelnet_pair(rank * 100003 + i) for i in range(n_pairs)]
-    else:
-        pairs = [synth_pair(rank * 100003 + i, args.points, args.shuffle) for i in range(n_pairs)]
-    batch = {'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in pairs],
-             'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in pairs]}
-    pair_ids = torch.arange(args.pairs, device=dev, dtype=torch.int32) + rank * args.pairs
+    lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, dev)
+    n_local = int(pair_ids.numel())
+    cfg, model, pairs, batch = build_workload(args.config, n_local, args.points, args.shuffle, rank, dev, dtype, args.parity_mode,
+                                              distinct=args.distinct_pairs if lomatch else None)
 
     def step():
-        return model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})['pose'][-1]
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    t0 = time.perf_counter()
-    poses = None
-    for _ in range(args.steps):
-        poses = step()
-    all_poses, all_ids = gather_poses(poses.reshape(-1, 12), pair_ids) if dist else (poses.reshape(-1, 12), pair_ids)
-    torch.cuda.synchronize()
-    if dist: dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    assert all_poses.shape[0] == args.pairs * world and torch.isfinite(all_poses).all()
-    ranks_seen = int(torch.unique(torch.div(all_ids, args.pairs, rounding_mode='floor')).numel())   # who entered the all_gather
+        poses, out = [], None
+        for lo, hi in chunks:
+            out = model({'src_xyz': batch['src_xyz'][lo:hi], 'tgt_xyz': batch['tgt_xyz'][lo:hi]})
+            poses.append(out['pose'][-1])
+        return (poses[0] if len(poses) == 1 else torch.cat(poses)), out
+    elapsed, all_poses, all_ids, last_out = timed_passes(args, dist, lomatch, pair_ids, step, torch.cuda.synchronize, dev)
+    assert all_poses.shape[0] == pairs_per_step and torch.isfinite(all_poses).all()
+    ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)                                      # who entered the all_gather
     assert ranks_seen == world, (ranks_seen, world)
 
     if rank == 0:
-        total_pairs = world * args.steps * args.pairs
+        total_pairs = args.steps * pairs_per_step
         mean_pts = [int(np.mean([len(s) for s, _ in pairs])), int(np.mean([len(t) for _, t in pairs]))]
         if args.config == 'modelnet':
             metric = f'point-cloud pairs/sec (ModelNet ~{mean_pts[0]} pts)'
@@ -344,20 +443,34 @@ def main():
             workload = 'BASELINE configs[2]: 3DMatch-size pairs, full KPConv encoder + 6-layer cross-attn + SVD'
             if args.points != 20000:
                 workload = f'BASELINE configs[4]-style stress: ~{args.points}-point clouds, conf/3dmatch.yaml pipeline'
+            if lomatch:
+                metric = 'point-cloud pairs/sec (3DLoMatch-like set, ~20k pts, overlap 10-30 %)'
+                workload = (f'BASELINE configs[3]: {args.total_pairs} 3DLoMatch-like pairs (overlap 10-30 %) sharded pair i -> rank i % {world}, '
+                            f'{per_fwd} pairs per forward, one RCCL pose all_gather per pass; a step = one pass over the set '
+                            f'({min(args.distinct_pairs, n_local)} distinct synthetic pairs per rank, cycled)')
+            if args.parity_mode:
+                workload += ' [PARITY MODE: reference row / tie orders reproduced on the GPU]'
         res = {
             'metric': metric, 'value': total_pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
-                       'arch': f'conf/{args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
+                       'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
                        'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
         }
+        if args.parity_pairs > 0:
+            # "pose err vs ref" (BASELINE.json metric): the last timed forward's outputs against the CPU oracle, >= 2 pairs
+            lo, hi = chunks[-1]
+            slots = sorted({0, hi - lo - 1} | set(range(1, min(args.parity_pairs, hi - lo) - 1)))
+            res['parity'] = parity_check(cfg, model, pairs[lo:hi], last_out, slots, args.parity_mode)
+            res['parity']['enforced'] = dtype == 'fp32'          # reduced-precision modes report the error, the 1e-4 gate is fp32's
+        fwd_batch = {k: v[chunks[0][0]:chunks[0][1]] for k, v in batch.items()}
         if not args.no_roofline:
-            r = measure_kpconv_roofline(model, batch)
-            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r) if args.config == '3dmatch' else None
+            r = measure_kpconv_roofline(model, fwd_batch)
+            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r) if (args.config == '3dmatch' and not args.parity_mode) else None
             gather = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
-            a = measure_attention(model, batch, cfg.nhead, cfg.d_embed, cfg.num_encoder_layers)
+            a = measure_attention(model, fwd_batch, cfg.nhead, cfg.d_embed, cfg.num_encoder_layers)
             peak = MFMA_BF16_PEAK_TFS
             att = {'bound': 'mfma', 'achieved': a['achieved_TFs'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': a['achieved_TFs'] / peak,
                    'traffic': None, 'detail': dict(a, operands={'fp32': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
@@ -368,10 +481,11 @@ def main():
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
         if dtype != 'fp32':
             # reduced-precision error, reported next to the number (parity is gated in fp32): same batch, float32-grade model
-            cfg32 = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{args.config}.yaml'))
+            from regtr_amd import RegTR, load_config
+            cfg32 = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{"3dmatch" if lomatch else args.config}.yaml'))
             m32 = RegTR(cfg32).to(dev).eval()
             m32.load_state_dict(model.state_dict())
-            sub = {'src_xyz': list(batch['src_xyz'][:16]), 'tgt_xyz': list(batch['tgt_xyz'][:16])}
+            sub = {'src_xyz': list(fwd_batch['src_xyz'][:16]), 'tgt_xyz': list(fwd_batch['tgt_xyz'][:16])}
             o32 = m32(dict(sub)); olo = model(dict(sub))
             nb = len(sub['src_xyz'])
             res['reduced_precision_error'] = {
@@ -379,11 +493,14 @@ def main():
                 'max_abs_correspondence': max(float((olo['src_kp_warped'][b] - o32['src_kp_warped'][b]).abs().max()) for b in range(nb)),
                 'max_abs_pose': float((olo['pose'] - o32['pose']).abs().max())}
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
-            res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(6 if args.config == '3dmatch' else 24)], cfg_name=args.config)
+            res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(24 if args.config == 'modelnet' else 6)],
+                                               cfg_name='3dmatch' if lomatch else args.config)
         print(json.dumps(res))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and res.get('parity', {}).get('enforced') and not res['parity']['ok']:
+        sys.exit(f"bench.py: PARITY FAILED -- {res['parity']}")
 
 
 if __name__ == '__main__':

@@ -49,6 +49,13 @@ extern "C" {
 #define REGTR_ERR_ARG (-2)
 #define REGTR_ERR_WORKSPACE (-3)
 
+/* ABI version of THIS header.  Entry points have gained arguments between versions (regtr_maxpool_gather, regtr_radius_query,
+ * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
+ * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
+ * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
+#define REGTR_ABI_VERSION 3
+int regtr_abi_version(void);
+
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
 
 size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds);

@@ -7,6 +7,8 @@ Cases
   3dmatch_kitchen : the full red-kitchen pair (18 977 + 19 084 pts), conf/3dmatch.yaml
   modelnet_postnorm : the ModelNet pair with pre_norm: False (forward_post), sa_val_has_pos_emb: False
   modelnet_attn_head : the ModelNet pair with direct_regress_coor: False (attention CorrespondenceDecoder)
+  3dmatch_crop_b2 : TWO ragged red-kitchen crop pairs in ONE forward (B = 2): the reference's padded (N_max, B, D) tokens +
+                    key_padding_mask path (regtr.py:147-172, transformers.py:197-226) against the packed-token path here
 Each file holds the float32 inputs, the reference module's outputs (reference row order) with
 weights = oracle.seeded_weights.seeded_state_dict(cfg, seed=0), and the reference C++'s
 per-level points / stack lengths.  `native_*` files hold raw outputs of the reference C++ ops.
@@ -76,6 +78,28 @@ def run_case(name, cfg_name, src, tgt, with_feats=False, overrides=None):
     print('  pose[-1]:\n', g['pose'][-1, 0])
 
 
+def run_batch_case(name, cfg_name, pairs):
+    """B > 1: the reference module on several ragged pairs in one forward (pad_sequence + key_padding_mask, regtr.py:147-166)."""
+    cfg = ref_loader.load_cfg(cfg_name)
+    model = ref_loader.build_model(cfg, 0)
+    model.load_state_dict(seeded_weights.seeded_state_dict(cfg, 0, K015_CENTER), strict=True)
+    batch = {'src_xyz': [torch.from_numpy(s) for s, _ in pairs], 'tgt_xyz': [torch.from_numpy(t) for _, t in pairs]}
+    with torch.no_grad():
+        out = model(batch)
+    meta = batch['kpconv_meta']
+    g = {'pose': out['pose'].numpy()}
+    for b, (s, t) in enumerate(pairs):
+        g[f'src_{b}'], g[f'tgt_{b}'] = s, t
+        for k in ('src_kp', 'tgt_kp', 'src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap'):
+            g[f'{k}_{b}'] = out[k][b].numpy()
+    for l, s in enumerate(meta['stack_lengths']):
+        g[f'lens_{l}'] = s.numpy().astype(np.int32)
+    g['points_last'] = meta['points'][-1].numpy()
+    g['neighbors_last'] = meta['neighbors'][-1].numpy().astype(np.int32)
+    np.savez_compressed(os.path.join(GOLD, f'{name}.npz'), **g)
+    print(name, 'pose', g['pose'].shape, [s.tolist() for s in meta['stack_lengths']])
+
+
 def overlaps_case(name, cfg_name, src, tgt):
     """The reference's own compute_overlaps (kpconv.py:540-566) on the reference Preprocessor's pyramid with seeded random
     level-0 masks -> tests/golden/overlaps_<name>.npz."""
@@ -120,6 +144,10 @@ def main():
     overlaps_case('3dmatch_crop', '3dmatch', c0, c5)
     if os.environ.get('GOLDEN_ONLY') == 'overlaps':
         return
+    if os.environ.get('GOLDEN_ONLY') in (None, 'batch'):
+        run_batch_case('3dmatch_crop_b2', '3dmatch', [(c0, c5), (crop(k0, 0.6), crop(k5, 0.7))])
+        if os.environ.get('GOLDEN_ONLY') == 'batch':
+            return
     run_case('modelnet_demo', 'modelnet', m0, m1)
     run_case('3dmatch_crop', '3dmatch', c0, c5, with_feats=True)
     run_case('3dmatch_kitchen', '3dmatch', k0, k5)

@@ -20,7 +20,10 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
+ABI_VERSION = 3          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+
 SIGNATURES = {
+    'regtr_abi_version': (_I, []),
     'regtr_grid_subsample_ws_bytes': (_Z, [_I, _I]),
     'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'regtr_grid_subsample_ordered_ws_bytes': (_Z, [_I, _I, _I]),
@@ -86,6 +89,11 @@ def lib():
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = _lib.regtr_abi_version()
+        if got != ABI_VERSION:
+            _lib = None
+            raise RuntimeError(f'{LIB_PATH} implements C-ABI version {got}, this binding was written for {ABI_VERSION}: rebuild with '
+                               '`python -m regtr_amd.build --force`')
     return _lib
 
 

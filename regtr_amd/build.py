@@ -32,7 +32,9 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     objdir = os.path.join(HERE, 'build', VARIANT) if VARIANT else os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    headers = ([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+               + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')])      # the public C-ABI header is a dependency too
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

@@ -485,11 +485,13 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
         k_moments<2, false, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A2, lda2, nullptr, 0.f, nullptr, K2, seg_off, nc, part2);
         k_tail_prepare<32, 64><<<pgrid, 256, 0, st>>>(part1, part2, seg_off, nc, W1, W2, N, eps, planes1, planes2, mean1, mean2,
                                                       (float2*)out_stats, n_clouds);
+        if (!rg_allow_dynamic_lds<k_tail_strip<2, 4, 2, 2, true>>(lds)) return RG_ERR_ARG;
         k_tail_strip<2, 4, 2, 2, true><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
     } else {
         k_moments<1, false, true><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, nullptr, 0.f, row_div1, K1, seg_off, nc, part1);
         k_tail_prepare<16, 0><<<pgrid, 256, 0, st>>>(part1, nullptr, seg_off, nc, W1, nullptr, N, eps, planes1, nullptr, mean1, nullptr,
                                                      (float2*)out_stats, n_clouds);
+        if (!rg_allow_dynamic_lds<k_tail_strip<1, 0, 2, 1, false>>(lds)) return RG_ERR_ARG;
         k_tail_strip<1, 0, 2, 1, false><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
     }
     RG_RETURN_IF_LAUNCH_FAILED();

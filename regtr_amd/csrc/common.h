@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "regtr_hip.h"      // the public C ABI: every definition below is checked against its declaration at compile time
+
 #define RG_WAVE 64
 
 // status codes of the C-ABI (include/regtr_hip.h)
@@ -15,6 +17,20 @@
     do {                                                  \
         if (hipGetLastError() != hipSuccess) return RG_ERR_LAUNCH; \
     } while (0)
+
+// A kernel launched with more dynamic LDS than the default limit: raise the kernel's limit on the CURRENT device, once per device
+// and kernel (a process-wide flag would leave a second GPU of the process at the default), thread-safe.  false = the device refused.
+template <auto Kernel>
+static inline bool rg_allow_dynamic_lds(size_t bytes)
+{
+    static unsigned long long ok_mask = 0;       // bit d: the attribute has been set on device d (devices >= 64: set every time)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (dev < 64 && (__atomic_load_n(&ok_mask, __ATOMIC_ACQUIRE) >> dev & 1)) return true;
+    if (hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    if (dev < 64) __atomic_fetch_or(&ok_mask, 1ull << dev, __ATOMIC_RELEASE);
+    return true;
+}
 
 static inline size_t rg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline int rg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

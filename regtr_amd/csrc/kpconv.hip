@@ -800,8 +800,7 @@ int regtr_kpconv_fused(const float* q_xyz, int nq, int ns, const int* nbr, int H
     FusedArgs g{q_xyz, nbr, x, s_xyzf, kernel_points, (const uint16_t*)planes, out, (size_t)Npad * Kp, nq, ns, H, KP, Kp, extent};
     constexpr int J = 10, HP = 4 * J;
     const size_t lds = (size_t)3 * FU_N * FU_WROW * 2 + (size_t)FU_WAVES * FU_K * 4 + 8 * 2 * 256 * 4 + (size_t)FU_WAVES * HP * 16 + 2 * FU_WAVES * 8;
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)k_kpconv_fused<J>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!rg_allow_dynamic_lds<k_kpconv_fused<J>>(lds)) return RG_ERR_ARG;
     const int grid = rg_xcd_grid(rg_cdiv(nq, FU_WAVES * FU_QPW));
     k_kpconv_fused<J><<<grid, FU_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(g);
     RG_RETURN_IF_LAUNCH_FAILED();

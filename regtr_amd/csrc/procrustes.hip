@@ -196,6 +196,8 @@ __global__ void __launch_bounds__(PT) k_procrustes(ProArgs g)
 
 extern "C" {
 
+int regtr_abi_version(void) { return REGTR_ABI_VERSION; }
+
 int regtr_weighted_procrustes(const float* kp, const float* corr, const float* logit, const int* seg_off, int n_pairs,
                               int n_total, int n_layers, float* pose, void* stream)
 {

@@ -101,19 +101,60 @@ class SyntheticPairs:
     """N deterministic synthetic 3DMatch-sized pairs (regtr_amd/synthetic.py) laid out like the 3DMatch test set
     (scene folders, cloud_bin_<k>.pth names) so that the est.log writer is exercised unchanged."""
 
-    def __init__(self, n, points=20000, pairs_per_scene=64):
-        self.n, self.points, self.pps = n, points, pairs_per_scene
+    def __init__(self, n, points=20000, pairs_per_scene=64, overlap=None):
+        self.n, self.points, self.pps, self.overlap = n, points, pairs_per_scene, overlap
 
     def __len__(self):
         return self.n
 
     def __getitem__(self, i):
         from .synthetic import synth_pair
-        src, tgt, pose = synth_pair(i, self.points, return_pose=True)
-        scene, k = i // self.pps, i % self.pps
-        return {'src_xyz': src, 'tgt_xyz': tgt, 'pose': pose, 'idx': i,
-                'src_path': f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k + 1}.pth',
-                'tgt_path': f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k}.pth'}
+        src, tgt, pose = synth_pair(i, self.points, return_pose=True, overlap=self.overlap)
+        sp, tp = _synthetic_paths(self, i)
+        return {'src_xyz': src, 'tgt_xyz': tgt, 'pose': pose, 'idx': i, 'src_path': sp, 'tgt_path': tp}
+
+
+def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank=0, world=1):
+    """Writes N synthetic pairs in the layout of the 3DMatch test set -- <root>/test/<scene>/cloud_bin_<k>.pth (torch-saved (N,3) float32
+    arrays, what data_loaders/threedmatch.py:74-75 torch.load()s) and an info pickle (keys rot, trans, src, tgt, overlap,
+    threedmatch.py:34-40) -- so that ThreeDMatchPairs, the loader thread and the est.log writer run exactly as on the real data set.
+    Rank r generates and writes pairs r, r + world, ...; the ground-truth poses are exchanged through small per-rank files, so the
+    pickle is complete on every rank.  -> info pickle path"""
+    src = SyntheticPairs(n, points, overlap=overlap)
+    t0 = time.perf_counter()
+    os.makedirs(root, exist_ok=True)
+    poses = {}
+    for i in range(rank, n, world):
+        it = src[i]
+        poses[i] = it['pose']
+        for rel, arr in zip(_synthetic_paths(src, i), (it['src_xyz'], it['tgt_xyz'])):
+            os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+            torch.save(arr, os.path.join(root, rel))
+    with open(os.path.join(root, f'poses.rank{rank}.pkl'), 'wb') as f:
+        pickle.dump(poses, f)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                      # every rank's files exist before anyone reads
+    for r in range(world):
+        if r != rank:
+            with open(os.path.join(root, f'poses.rank{r}.pkl'), 'rb') as f:
+                poses.update(pickle.load(f))
+    infos = {'rot': [], 'trans': [], 'src': [], 'tgt': [], 'overlap': []}
+    for i in range(n):
+        sp, tp = _synthetic_paths(src, i)
+        infos['rot'].append(poses[i][:, :3].astype(np.float64)); infos['trans'].append(poses[i][:, 3:].astype(np.float64))
+        infos['src'].append(sp); infos['tgt'].append(tp); infos['overlap'].append(0.0)
+    path = os.path.join(root, f'test_info.rank{rank}.pkl')
+    with open(path, 'wb') as f:
+        pickle.dump(infos, f)
+    if logger:
+        logger.info(f'{n} synthetic pairs materialised under {root} in {time.perf_counter() - t0:.1f} s')
+    return path
+
+
+def _synthetic_paths(src, i):
+    scene, k = i // src.pps, i % src.pps
+    return (f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k + 1}.pth', f'test/synthetic-scene{scene:03d}/cloud_bin_{2 * k}.pth')
 
 
 # ------------------------------------------------------------------------------------------------------ streaming

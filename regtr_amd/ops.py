@@ -152,7 +152,7 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     ldc = out.stride(0) if M > 1 else N
     n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
     if (sw is not None and sw.planes is not None and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm
-            and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
+            and L.regtr_gemm_x3_supported(M, N, K) and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
         nb = L.regtr_gemm_x3_ws_bytes(M, N, K)
         ws = _ws(nb, a.device) if nb else None
         R = L.regtr_gemm_x3_stat_tile_rows(M, N, K) if (want_stats is not None and M > 0) else 0
@@ -191,11 +191,14 @@ def tile_segments(seg_off, M, rows):
     cache = getattr(seg_off, '_regtr_tiles', None)
     if cache is None:
         cache = seg_off._regtr_tiles = {}
-    t = cache.get((M, rows))
+    key = (M, rows, seg_off.data_ptr(), seg_off._version)      # an offsets tensor refilled in place must not serve stale cloud boundaries
+    t = cache.get(key)
     if t is None:
         t = torch.empty(((M + rows - 1) // rows, 4), dtype=torch.int32, device=seg_off.device)
         check(_lib.lib().regtr_tile_segments(iptr(seg_off), seg_off.numel() - 1, M, rows, iptr(t), stream()), 'regtr_tile_segments')
-        cache[(M, rows)] = t
+        for k in [k for k in cache if k[2:] != key[2:]]:           # tables of the tensor's earlier contents
+            del cache[k]
+        cache[key] = t
     return t
 
 

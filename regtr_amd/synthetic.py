@@ -66,14 +66,20 @@ def random_se3(rng, rot_deg=45.0, trans=0.5):
     return R, t
 
 
-def synth_pair(pair_id, pts_per_cloud=20000, shuffle=False, return_pose=False):
+def synth_pair(pair_id, pts_per_cloud=20000, shuffle=False, return_pose=False, overlap=None):
     """Two overlapping views (72 % of the scene each) of one synthetic room, the target moved by a random SE(3) (rotation
     <= 45 deg, |t| <= 0.5 m) and both jittered by N(0, 5 mm) (3dmatch.yaml:7).  Deterministic in pair_id.
-    return_pose: also return the ground-truth (3, 4) transform taking src into the tgt frame."""
+    return_pose: also return the ground-truth (3, 4) transform taking src into the tgt frame.
+    overlap: fraction of each view's extent shared with the other (default None = the 3DMatch-like 0.61); 'lomatch' draws it
+    uniformly from [0.10, 0.30] per pair, the overlap range of the 3DLoMatch test list; the
+    room grows so that each view still holds ~pts_per_cloud points."""
     rng = np.random.default_rng(1000 + pair_id)
-    scene, X = synth_scene(rng, int(pts_per_cloud / 0.72))
-    src = scene[scene[:, 0] < 0.72 * X]
-    tgt = scene[scene[:, 0] > 0.28 * X]
+    if overlap == 'lomatch':
+        overlap = float(np.random.default_rng(5000 + pair_id).uniform(0.10, 0.30))
+    f = 0.72 if overlap is None else 1.0 / (2.0 - float(overlap))         # each view spans [0, f] / [1 - f, 1] of the room's length
+    scene, X = synth_scene(rng, int(pts_per_cloud / f))
+    src = scene[scene[:, 0] < f * X]
+    tgt = scene[scene[:, 0] > (1.0 - f) * X]
     R, t = random_se3(rng)
     tgt = tgt @ R.T + t + rng.normal(scale=0.005, size=tgt.shape)        # augment_noise 0.005 (3dmatch.yaml:7)
     src = src + rng.normal(scale=0.005, size=src.shape)

@@ -38,6 +38,11 @@ parser.add_argument('--batch', type=int, default=8, help='pairs per forward')
 parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.root (folder holding test/<scene>/cloud_bin_*.pth)')
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
+parser.add_argument('--materialize', type=str, default=None,
+                    help='with --synthetic N: first write the N pairs as <DIR>/test/<scene>/cloud_bin_*.pth + an info pickle (the 3DMatch test-set '
+                         'layout, data_loaders/threedmatch.py:74-75) and run the DATASET path over them: .pth loads on the worker thread, pinned '
+                         'H2D copies, forwards, pose gather, est.log writes -- the end-to-end figure of the harness')
+parser.add_argument('--overlap', type=str, default=None, help="synthetic pairs: 'lomatch' = 10-30 %% overlap (3DLoMatch-like)")
 parser.add_argument('--max_pairs', type=int, default=None)
 parser.add_argument('--neighbor_order', choices=('nearest', 'index'), default=None,
                     help='neighbour selection rule: nearest = the reference CPU Preprocessor (default), index = its PreprocessorGPU '
@@ -113,8 +118,12 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     # pairs
-    if opt.synthetic > 0:
-        pairs = harness.SyntheticPairs(opt.synthetic, points=20000 if cfg.dataset == '3dmatch' else 717)
+    if opt.synthetic > 0 and opt.materialize:
+        info = harness.materialize_synthetic(opt.materialize, opt.synthetic, overlap=opt.overlap, logger=logger if rank == 0 else None,
+                                             rank=rank, world=world)
+        pairs = harness.ThreeDMatchPairs(info, opt.materialize)
+    elif opt.synthetic > 0:
+        pairs = harness.SyntheticPairs(opt.synthetic, points=20000 if cfg.dataset == '3dmatch' else 717, overlap=opt.overlap)
     elif cfg.dataset == '3dmatch':
         info = opt.info or os.path.join('datasets', '3dmatch', f'test_{opt.benchmark}_info.pkl')
         cfg_root = cfg.get('root', None)         # the shipped regtr_amd/conf/*.yaml carry no dataset root: --data_root supplies it
@@ -136,17 +145,22 @@ def main():
     else:
         logger.warning('No checkpoint given. Will perform inference using random weights')
 
+    t_run = time.perf_counter()
     poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs)
+    from_files = isinstance(pairs, harness.ThreeDMatchPairs)
     if rank == 0:
         recs, gts = [], []
         for pose, i in zip(poses, ids):
-            meta = pairs[int(i)] if opt.synthetic > 0 else {'src_path': pairs.infos['src'][int(i)], 'tgt_path': pairs.infos['tgt'][int(i)],
+            meta = pairs[int(i)] if not from_files else {'src_path': pairs.infos['src'][int(i)], 'tgt_path': pairs.infos['tgt'][int(i)],
                                                             'pose': np.concatenate([pairs.infos['rot'][int(i)], pairs.infos['trans'][int(i)].reshape(3, 1)], 1)}
             recs.append({'src_path': meta['src_path'], 'tgt_path': meta['tgt_path'], 'pose': pose})
             gts.append(meta['pose'])
         if cfg.dataset == '3dmatch':
             harness.write_est_log(opt.log_path, opt.benchmark, recs)
+            t_all = time.perf_counter() - t_run
             logger.info(f'est.log files written under {os.path.join(opt.log_path, opt.benchmark)}')
+            logger.info(f'[End to end] {len(ids)} pairs, {"files -> " if from_files else "generator -> "}H2D -> forward -> pose gather -> est.log: '
+                        f'{t_all:.2f} s = {len(ids) / t_all:.1f} pairs/s on {timing["world"]} GPU(s), batch {opt.batch}')
             gt_folder = os.path.join(opt.benchmark_dir, opt.benchmark)
             complete = opt.max_pairs is None or opt.max_pairs <= 0 or opt.max_pairs >= len(pairs)
             if opt.synthetic == 0 and os.path.isdir(gt_folder) and not complete:

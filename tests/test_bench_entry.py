@@ -29,3 +29,12 @@ def test_world_size_mismatch_is_an_error():
     assert r.returncode != 0 and 'refusing' in (r.stderr + r.stdout)
     r = _run(['--gpus', '1', '--stub-backend', 'gloo', '--steps', '1', '--pairs', '2'])
     assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])['n_gpus'] == 1
+
+
+def test_lomatch_set_is_sharded_and_gathered_every_pass():
+    """--config lomatch (BASELINE configs[3]): 23 pairs over 2 ranks (12 + 11: ragged shards), 5 per forward (ragged last forward),
+    every pose back on every rank in pair-id order after each pass; strong scaling is what the line says."""
+    r = _run(['--gpus', '2', '--config', 'lomatch', '--total-pairs', '23', '--pairs', '5', '--steps', '2', '--warmup', '1', '--stub-backend', 'gloo'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 2 and d['pairs_per_step'] == 23 and d['forwards_per_step_rank0'] == 3 and d['scaling'] == 'strong'

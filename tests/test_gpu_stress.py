@@ -145,27 +145,8 @@ def test_large_batch_paths_agree_with_per_op_paths():
 
 
 def _ref_canonical_meta(pts_list, cfg):
-    """kpconv_meta in the product's canonical orders at stress size: first-appearance subsampling from the (linear-time) C++
-    oracle, neighbour sets from the unmodified reference C++ (KD-tree) re-ordered to (d2, index) and cut at K."""
-    from oracle import native
-    pts = np.concatenate(pts_list).astype(np.float32); lens = np.array([len(p) for p in pts_list], np.int32)
-    limits = cfg['neighborhood_limits']
-    r = cfg['first_subsampling_dl'] * cfg['conv_radius']
-    meta = {k: [] for k in ('points', 'neighbors', 'pools', 'upsamples', 'stack_lengths')}
-    n_levels = 1 + sum(('strided' in b or 'pool' in b) for b in cfg['architecture'])
-    for l in range(n_levels):
-        K = limits[l]
-        conv = canon_table(native.ref_batch_query(pts, pts, lens, lens, r), pts, pts, len(pts), K)
-        if l + 1 < n_levels:
-            sub, sl = native.grid_subsample(pts, lens, 2 * r / cfg['conv_radius'])
-            pool = canon_table(native.ref_batch_query(sub, pts, sl, lens, r), sub, pts, len(pts), K)
-        else:
-            sub, sl, pool = np.zeros((0, 3), np.float32), np.zeros(0, np.int32), np.zeros((0, 1), np.int32)
-        meta['points'].append(torch.from_numpy(pts)); meta['neighbors'].append(torch.from_numpy(conv.astype(np.int64)))
-        meta['pools'].append(torch.from_numpy(pool.astype(np.int64))); meta['upsamples'].append(torch.zeros((0, 1), dtype=torch.int64))
-        meta['stack_lengths'].append(torch.from_numpy(lens.astype(np.int64)))
-        pts, lens, r = sub, sl, r * 2
-    return meta
+    from oracle.canonical import canonical_meta
+    return canonical_meta(pts_list, cfg)
 
 
 def test_stress_100k_full_tables_and_forward_vs_oracle():

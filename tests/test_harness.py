@@ -32,6 +32,22 @@ def test_ply_reader_ascii_and_binary(tmp_path):
     assert np.array_equal(load_point_cloud(str(tmp_path / 'c.pth')), pts)
 
 
+def test_materialized_synthetic_set_reads_back_through_the_dataset_path(tmp_path):
+    """test.py --synthetic N --materialize DIR: the pairs written as 3DMatch-layout .pth files + info pickle are what the generator
+    yields, and the dataset class / prefetcher deliver them in order (the end-to-end harness measurement runs over these files)."""
+    from regtr_amd import harness
+    info = harness.materialize_synthetic(str(tmp_path), 3, points=1500, overlap='lomatch')
+    ds = harness.ThreeDMatchPairs(info, str(tmp_path))
+    gen = harness.SyntheticPairs(3, points=1500, overlap='lomatch')
+    assert len(ds) == 3
+    for i in range(3):
+        a, b = ds[i], gen[i]
+        assert np.array_equal(a['src_xyz'], b['src_xyz']) and np.array_equal(a['tgt_xyz'], b['tgt_xyz'])
+        assert np.allclose(a['pose'], b['pose']) and a['src_path'] == b['src_path'] and a['tgt_path'] == b['tgt_path']
+    got = [it['idx'] for bt in harness.Prefetcher(ds, [0, 1, 2], 2, torch.device('cpu')) for it in bt['items']]
+    assert got == [0, 1, 2]
+
+
 def test_est_log_format(tmp_path):
     """Block layout of generic_reg_model.py:276-281: 'tgt\\tsrc\\t-1' then four tab-separated rows with 12 decimals."""
     from regtr_amd.harness import write_est_log

@@ -88,6 +88,25 @@ def test_float_restatement_vs_reference_golden(case, cfgn, overrides):
         assert np.abs(out['src_feat'][0][-1].numpy() - g['src_feat_last']).max() < 5e-5
 
 
+def test_float_restatement_vs_reference_golden_batch2():
+    """B = 2 ragged pairs in one forward: the reference pads the tokens to (N_max, B, D) and masks the padded keys (regtr.py:147-172,
+    transformers.py:197-226); the restatement runs every pair on its own packed tokens.  Same outputs (golden: the real module)."""
+    if not native.have_ref():
+        pytest.skip('needs oracle/_ref for the reference row order')
+    g = gold('3dmatch_crop_b2')
+    cfg = load_cfg('3dmatch')
+    sd = seeded_sd(cfg)
+    with torch.no_grad():
+        out = regtr_ref.regtr_forward(sd, cfg, [g['src_0'], g['src_1']], [g['tgt_0'], g['tgt_1']], use_ref_cpp=True)
+    assert np.array_equal(out['kpconv_meta']['points'][-1].numpy(), g['points_last'])
+    assert np.array_equal(out['kpconv_meta']['neighbors'][-1].numpy(), g['neighbors_last'])
+    for b in range(2):
+        assert np.array_equal(out['src_kp'][b].numpy(), g[f'src_kp_{b}']) and np.array_equal(out['tgt_kp'][b].numpy(), g[f'tgt_kp_{b}'])
+        for k in ('src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap'):
+            assert np.abs(out[k][b].numpy() - g[f'{k}_{b}']).max() < 5e-5, (k, b)
+    assert np.abs(out['pose'].numpy() - g['pose']).max() < 5e-5
+
+
 def test_reference_order_pyramid_matches_golden():
     """Level points of the kitchen pair in the reference's order are bit exact at every level."""
     g = gold('3dmatch_kitchen')
@@ -132,3 +151,21 @@ def test_ball_query_first_k_properties():
         want = list(ball[:K]) + [len(s)] * (K - min(K, len(ball)))
         assert list(t[i]) == want
     assert (np.diff(np.where(t < len(s), t, len(s) + np.arange(K)), axis=1) > 0).all()      # ascending inside a row
+
+
+def test_pair_tables_cut_from_a_batch_equal_the_pair_alone():
+    """oracle/canonical.py: the rows of one pair cut out of a batched kpconv_meta and re-indexed == canonical_meta of that pair alone
+    (preprocessing is per cloud) -- the helper the bench-batch GPU test relies on, checked here on the CPU restatement."""
+    from oracle import canonical
+    from regtr_amd.synthetic import synth_pair
+    cfg = load_cfg('3dmatch')
+    pairs = [synth_pair(i, 3000, overlap='lomatch' if i else None) for i in range(3)]
+    meta = regtr_ref.preprocess([s for s, _ in pairs] + [t for _, t in pairs], cfg)
+    for b in range(3):
+        cm = canonical.canonical_meta(list(pairs[b]), cfg)
+        pt = canonical.pair_tables_of_batch(meta, 3, b)
+        for l in range(len(cm['points'])):
+            assert np.array_equal(pt['points'][l], cm['points'][l].numpy())
+            assert np.array_equal(pt['neighbors'][l], cm['neighbors'][l].numpy()), (b, l)
+            if pt['pools'][l] is not None:
+                assert np.array_equal(pt['pools'][l], cm['pools'][l].numpy()), (b, l)

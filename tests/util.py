@@ -54,21 +54,8 @@ def canon_rows(idx, q, s, pad):
 
 
 def canon_table(idx, q, s, pad, K=None):
-    """canon_rows, vectorised (for 100k-row tables): every row sorted by (d2 in the reference's float32 arithmetic, index),
-    padding last; optionally cut / padded to K columns."""
-    idx = np.asarray(idx).astype(np.int64)
-    s_pad = np.concatenate([np.asarray(s, np.float32), np.zeros((1, 3), np.float32)])
-    isp = idx == pad
-    d = q[:, None, :].astype(np.float32) - s_pad[np.minimum(idx, len(s_pad) - 1)]
-    d2 = ((np.float32(0) + d[..., 0] * d[..., 0]) + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
-    key = (d2.view(np.uint32).astype(np.int64) << 32) | idx
-    key[isp] = np.iinfo(np.int64).max
-    out = np.take_along_axis(idx, np.argsort(key, axis=1, kind='stable'), axis=1)
-    if K is not None:
-        if out.shape[1] < K:
-            out = np.concatenate([out, np.full((out.shape[0], K - out.shape[1]), pad, np.int64)], 1)
-        out = out[:, :K]
-    return out.astype(np.int32)
+    from oracle.canonical import canon_table as f
+    return f(idx, q, s, pad, K)
 
 
 def to_dev(a, dtype=None):
