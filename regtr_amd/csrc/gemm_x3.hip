@@ -340,6 +340,422 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     }
 }
 
+typedef float x3_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void x3_asm_dma16(const void* gsrc, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ROW-STRIP, ALL-DMA form of the same product for the tall problems (the launcher's choice from a few hundred 128-row tiles on,
+// K a multiple of 32, no InstanceNorm folded into A).  A workgroup is four waves; wave w owns rows [32 w, 32 w + 32) of the 128-row
+// tile and ALL 32 CW columns, so no other wave ever needs its A rows:
+//   * the raw float32 A rows arrive by LDS-DMA in whole 128-byte lines (each wave fetches exactly its own 32 rows: the A stream needs
+//     no barrier, only the wave's own counted wait) into an XOR-swizzled image (16-byte chunk c of row r at c ^ ((r >> 1) & 7): the
+//     two ds_read_b128 of a fragment are conflict free), and are split into the three bf16 planes AT FRAGMENT TIME, exactly once
+//     per element (the all-DMA form of the tiled kernel lost there: every column wave repeated the split);
+//   * the weight planes -- shared by the four waves -- are staged by LDS-DMA into the other half of the two-slot ring; one barrier per
+//     k-tile (the tiled kernel: two, plus an A store pass of 5.5 VALU + one 8-byte LDS store per element per COLUMN tile);
+//   * 0.5 16-byte LDS reads per MFMA (tiled: 0.75).
+// What was measured on the way (MI355X, RegTR's shapes at 64 pairs per forward, tools/x3_bench.py; tables in profiles/r03_x3_*):
+//   * the same strip layout with A loaded by each lane in fragment shape straight into registers (no LDS for A), compiler-scheduled:
+//     equal to the tiled kernel (sum over 18 shapes 5.34 vs 5.05 ms).  Ablations: no A loads -30 %, no barrier / weight DMA -17 %, no
+//     split -5 %, no fragment reads -5 %, MFMAs alone 2.3x faster -- every cost ADDS, nothing overlaps;
+//   * that form with both operand streams issued from inline asm and a two-tile-deep register prefetch of A (counted vmcnt across
+//     the barrier): -3 %.  Phase clocks (s_memtime) per k-tile and wave: issuing 6 weight DMAs + 4 fragment-shaped A loads 1100-1650
+//     cycles (each A load gathers 32 different 128-byte lines; the wave issues in order, so no MFMA goes out meanwhile), 48 MFMAs 750,
+//     wait + barrier 1000, split 150;
+//   * A by DMA as well (this kernel's data path), compiler-scheduled k loop: 505 vs 545 us on the level-3 KPConv contraction; PMC:
+//     matrix pipe 44 % busy, waves 48 % of their cycles in issue stalls, 26 % in waits, 5 VALU per MFMA at 128 x 64 tiles;
+//     tile / split-K sweeps (3 tiles x 5 splits) move nothing by more than 5 %: the bound is per-CU, not occupancy or quantisation;
+//   * the .s showed why: hipcc hoists each step's split (44 dependent VALU) in front of that step's MFMAs and issues every fragment
+//     read right before its consumer (`ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma x5`); __builtin_amdgcn_sched_group_barrier did not
+//     change the order.  Hence the hand-scheduled loop below (NP = 3): -11 ... -14 % on the long-K shapes.
+// ---- single-instruction asm wrappers of the hand-scheduled k loop (k_gemm_x3d, NP = 3): volatile asm statements keep their
+// program order, which is the point -- hipcc's list scheduler hoists the split ahead of the MFMAs and issues each fragment read
+// right in front of its consumer (the .s of the plain-C++ loop: `ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma x5`), and
+// sched_group_barrier did not change that.  Waits are counted by hand: LDS operations return in order.
+__device__ __forceinline__ void x3h_mfma(floatx16& c, const bf16x8& a, const bf16x8& b)
+{
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+template <int OFF>
+__device__ __forceinline__ void x3h_lds128(uint4& d, unsigned addr)
+{
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+// first half of the exact three-way split of a float pair: p0 = bf16 pair, (ra, rb) = residuals
+__device__ __forceinline__ void x3h_split_a(float a, float b, unsigned& p0, float& ra, float& rb)
+{
+    unsigned t0, t1;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %5, %6\n\t"
+                 "v_lshlrev_b32 %3, 16, %0\n\t"
+                 "v_and_b32 %4, 0xffff0000, %0\n\t"
+                 "v_sub_f32 %1, %5, %3\n\t"
+                 "v_sub_f32 %2, %6, %4"
+                 : "=&v"(p0), "=&v"(ra), "=&v"(rb), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b));
+}
+// second half: p1 = bf16 pair of the residuals, p2 = bf16 pair of what is left
+__device__ __forceinline__ void x3h_split_b(float ra, float rb, unsigned& p1, unsigned& p2)
+{
+    unsigned t0, t1;
+    float sa, sb;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %6, %7\n\t"
+                 "v_lshlrev_b32 %2, 16, %0\n\t"
+                 "v_and_b32 %3, 0xffff0000, %0\n\t"
+                 "v_sub_f32 %4, %6, %2\n\t"
+                 "v_sub_f32 %5, %7, %3\n\t"
+                 "v_cvt_pk_bf16_f32 %1, %4, %5"
+                 : "=&v"(p1), "=&v"(p2), "=&v"(t0), "=&v"(t1), "=&v"(sa), "=&v"(sb) : "v"(ra), "v"(rb));
+}
+#define X3H_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory")
+#ifndef X3D_HAND
+#define X3D_HAND 1       // development (REGTR_VARIANT_FLAGS=-DX3D_HAND=0): the compiler-scheduled k loop for A/B runs
+#endif
+
+template <int CW, bool SOUT, int NP = 3>
+__global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
+{
+    constexpr int MW = 4, BM = 32 * MW, BN = 32 * CW;
+    constexpr int A_BYTES = BM * XBK * 4;                      // raw float32 rows of one k-tile: 16 KiB
+    constexpr int B_BYTES = NP * BN * XROW;
+    constexpr int NQ = B_BYTES / 1024 / MW, NA = A_BYTES / 1024 / MW;
+    static_assert(NQ * 1024 * MW == B_BYTES && NA == 4, "operand tiles must split evenly over the waves");
+    __shared__ __align__(1024) unsigned char sm[2 * (A_BYTES + B_BYTES)];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int tile_m, tile_n;
+    {
+        const int nc = g.N / BN, b = blockIdx.x, x = b & 7, q = b >> 3;       // XCD-aware map, as in k_gemm_x3
+        tile_n = q % nc;
+        tile_m = (q / nc) * 8 + x;
+        if (tile_m * BM >= g.M) return;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nk = (k_end - k_begin) / XBK;                    // whole k-tiles only (the launcher checks)
+
+    int s_lo = 0, s_hi = 0, s_lo_begin = 0, s_lo_end = 0;
+    if (SOUT) {
+        if (g.tile_info) {
+            const int4 ti = g.tile_info[tile_m];
+            s_lo = ti.x; s_hi = ti.y; s_lo_begin = ti.z; s_lo_end = ti.w;
+        } else {
+            const int row_last = min(m0 + BM, g.M) - 1;
+            s_lo = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, m0);
+            s_hi = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, row_last);
+            s_lo_begin = g.stat_seg_off[s_lo]; s_lo_end = g.stat_seg_off[s_lo + 1];
+        }
+    }
+    // ---- A DMA: instruction q of this wave fills rows 32 wave + 8 q + (lane >> 3), LDS slot lane & 7 <- source chunk slot ^ ((row >> 1) & 7)
+    const float* a_src[NA];
+#pragma unroll
+    for (int q = 0; q < NA; q++) {
+        const int r = wave * 32 + q * 8 + (lane >> 3);
+        const int row = m0 + r, rc = row < g.M ? row : g.M - 1;    // rows past M compute garbage that the epilogue never stores
+        a_src[q] = g.A + (size_t)rc * g.lda + k_begin + (((lane & 7) ^ ((r >> 1) & 7)) * 4);
+    }
+    const uint16_t* b_src[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int sidx = (wave * NQ + q) * 64 + lane;
+        const int p = sidx / (BN * 4), r = sidx % (BN * 4), n = r >> 2, kc = (r & 3) ^ ((n >> 2) & 3);
+        b_src[q] = g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + kc * 8 + k_begin;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(x3_lds_ptr)(&sm[0]);
+    auto dma_tile = [&](int kt, int buf) {                    // operands of k-tile kt -> ring slot buf; A first: the wave reads its own rows early
+        const unsigned bb = lds_base + (unsigned)buf * (A_BYTES + B_BYTES);
+#pragma unroll
+        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), bb + (unsigned)(wave * NA + q) * 1024u);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), bb + A_BYTES + (unsigned)(wave * NQ + q) * 1024u);
+    };
+    // fragment addresses: A row 32 wave + l31, 16-byte chunks 4 ks + 2 hi (+ 1), swizzled; B as in k_gemm_x3
+    unsigned fa_off[2][2], f_off[2];
+    {
+        const unsigned r = (unsigned)wave * 32u + (unsigned)l31, sw = (r >> 1) & 7u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) fa_off[ks][h] = r * 128u + ((((unsigned)(4 * ks + 2 * hi + h)) ^ sw) * 16u);
+            f_off[ks] = (unsigned)l31 * XROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
+        }
+    }
+    floatx16 acc[CW];
+#pragma unroll
+    for (int j = 0; j < CW; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    if constexpr (NP == 3 && X3D_HAND) {
+    // ---- hand-scheduled k loop.  Per 16-k step and column block: three fragment reads of the NEXT block are issued, the wait
+    // leaves exactly those in flight, then the block's six MFMAs go out with the two halves of one float pair's split (of the next
+    // step's A piece) behind the first two.  Register sets are static -- fa[2] (step parity), fb[2] (block parity), raw[2] -- and
+    // the ring slot is carried in the ADDRESS registers (toggled by one subtraction per tile), so the loop body is one tile and no
+    // accumulator is ever copied between differently-allocated halves of an unrolled loop.
+    constexpr int SLOT = A_BYTES + B_BYTES;
+    constexpr int PJ = 4 / CW;
+    static_assert(CW == 2 || CW == 4, "the split is spread over 2 or 4 column blocks");
+    // per-lane LDS byte addresses: weights of the CURRENT slot at step ks; A piece halves of the NEXT slot
+    unsigned vb[2], va[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        vb[ks] = lds_base + A_BYTES + f_off[ks];
+        va[ks][0] = lds_base + SLOT + fa_off[ks][0];
+        va[ks][1] = lds_base + SLOT + fa_off[ks][1];
+    }
+    unsigned dma_dst = lds_base + SLOT;                         // ring slot the next tile streams into (wave-uniform)
+    const unsigned tog = 2u * lds_base + SLOT;                  // slot address toggle: x -> tog + 2 (x's offset within a slot) - x
+    uint4 fbq[2][3], rawq[2][2];          // weight fragments (block parity, plane); A piece halves (step parity, half)
+    unsigned pl[2][3][4];                  // split planes being built (step parity, plane, float pair)
+    bf16x8 fa[2][3];
+    float ra = 0.f, rb = 0.f;
+#define X3H_FB(KS, J, SET) do { x3h_lds128<(0 * BN + (J) * 32) * XROW>(fbq[SET][0], vb[KS]); \
+                                x3h_lds128<(1 * BN + (J) * 32) * XROW>(fbq[SET][1], vb[KS]); \
+                                x3h_lds128<(2 * BN + (J) * 32) * XROW>(fbq[SET][2], vb[KS]); } while (0)
+#define X3H_RAW(KS, SET) do { x3h_lds128<0>(rawq[SET][0], va[KS][0]); x3h_lds128<0>(rawq[SET][1], va[KS][1]); } while (0)
+#define X3H_PAIR_A(SET, Q) do { const uint4 v_ = rawq[SET][(Q) >> 1]; \
+        x3h_split_a(__uint_as_float(((Q) & 1) ? v_.z : v_.x), __uint_as_float(((Q) & 1) ? v_.w : v_.y), pl[SET][0][Q], ra, rb); } while (0)
+#define X3H_PAIR_B(SET, Q) x3h_split_b(ra, rb, pl[SET][1][Q], pl[SET][2][Q])
+#define X3H_PACK(SET) do { _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++) \
+        fa[SET][p_] = __builtin_bit_cast(bf16x8, make_uint4(pl[SET][p_][0], pl[SET][p_][1], pl[SET][p_][2], pl[SET][p_][3])); } while (0)
+    // the six MFMAs of column block J from fa[FS] x fb[CS] (smallest terms first) with the split of pairs PJ J .. of raw[FS ^ 1] behind them
+#define X3H_BLOCK(J, FS, CS) do { \
+        const bf16x8 b0_ = __builtin_bit_cast(bf16x8, fbq[CS][0]), b1_ = __builtin_bit_cast(bf16x8, fbq[CS][1]), b2_ = __builtin_bit_cast(bf16x8, fbq[CS][2]); \
+        x3h_mfma(acc[J], fa[FS][2], b0_); X3H_PAIR_A((FS) ^ 1, PJ * (J)); \
+        x3h_mfma(acc[J], fa[FS][1], b1_); X3H_PAIR_B((FS) ^ 1, PJ * (J)); \
+        x3h_mfma(acc[J], fa[FS][0], b2_); if (PJ == 2) X3H_PAIR_A((FS) ^ 1, PJ * (J) + 1); \
+        x3h_mfma(acc[J], fa[FS][1], b0_); if (PJ == 2) X3H_PAIR_B((FS) ^ 1, PJ * (J) + 1); \
+        x3h_mfma(acc[J], fa[FS][0], b1_); \
+        x3h_mfma(acc[J], fa[FS][0], b0_); } while (0)
+    // one 16-k step KS of the current slot using fa[FS]; at its end fa[FS ^ 1] is complete.  _MID: the first block of the slot's next
+    // step is prefetched behind the last block; _END: last step of a tile (the next tile's fragments need the barrier first).  LDS
+    // operations return in order: with the next block's three reads just issued, lgkmcnt(3) = everything older has landed (the current
+    // block's fragments and, in the tile's second step, the four A-piece reads issued in front of it).
+#define X3H_STEP_MID(KS, FS, NKS) do { \
+        if constexpr (CW == 4) { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCK(0, FS, 0); \
+            X3H_FB(KS, 2, 0); X3H_LGKM(3); X3H_BLOCK(1, FS, 1); \
+            X3H_FB(KS, 3, 1); X3H_LGKM(3); X3H_BLOCK(2, FS, 0); \
+            X3H_FB(NKS, 0, 0); X3H_LGKM(3); X3H_BLOCK(3 % CW, FS, 1); \
+        } else { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCK(0, FS, 0); \
+            X3H_FB(NKS, 0, 0); X3H_LGKM(3); X3H_BLOCK(1, FS, 1); \
+        } \
+        X3H_PACK((FS) ^ 1); } while (0)
+#define X3H_STEP_END(KS, FS) do { \
+        if constexpr (CW == 4) { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCK(0, FS, 0); \
+            X3H_FB(KS, 2, 0); X3H_LGKM(3); X3H_BLOCK(1, FS, 1); \
+            X3H_FB(KS, 3, 1); X3H_LGKM(3); X3H_BLOCK(2, FS, 0); \
+            X3H_LGKM(0); X3H_BLOCK(3 % CW, FS, 1); \
+        } else { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCK(0, FS, 0); \
+            X3H_LGKM(0); X3H_BLOCK(1, FS, 1); \
+        } \
+        X3H_PACK((FS) ^ 1); } while (0)
+#define X3D_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define X3D_OWN_A() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQ) : "memory")
+    auto dma_next = [&](int kt) {                              // operands of k-tile kt -> the slot at dma_dst; A first (read early by this wave)
+#pragma unroll
+        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), dma_dst + (unsigned)(wave * NA + q) * 1024u);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), dma_dst + A_BYTES + (unsigned)(wave * NQ + q) * 1024u);
+    };
+    dma_tile(0, 0);
+    X3D_SYNC();
+    // pipeline prologue: fa[0] = step 0 of tile 0 (split here, unhidden, once), raw[1] = step 1's piece -- both from slot 0
+    {
+        unsigned a00 = lds_base + fa_off[0][0], a01 = lds_base + fa_off[0][1], a10 = lds_base + fa_off[1][0], a11 = lds_base + fa_off[1][1];
+        x3h_lds128<0>(rawq[0][0], a00); x3h_lds128<0>(rawq[0][1], a01);
+        x3h_lds128<0>(rawq[1][0], a10); x3h_lds128<0>(rawq[1][1], a11);
+    }
+    X3H_LGKM(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { X3H_PAIR_A(0, q); X3H_PAIR_B(0, q); }
+    X3H_PACK(0);
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) dma_next(kt + 1);
+        X3H_FB(0, 0, 0);
+        X3H_STEP_MID(0, 0, 1);
+        X3D_OWN_A();                                           // this wave's A rows of tile kt + 1 (stale data after the last tile)
+        X3H_RAW(0, 0);
+        X3H_RAW(1, 1);
+        X3H_STEP_END(1, 1);
+        X3D_SYNC();                                            // tile kt + 1 has landed everywhere; the current slot is free
+        // swap the ring slots: weights of the current slot <-> A pieces / DMA target of the next
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            vb[ks] = tog + 2u * (A_BYTES + f_off[ks]) - vb[ks];
+            va[ks][0] = tog + 2u * fa_off[ks][0] - va[ks][0];
+            va[ks][1] = tog + 2u * fa_off[ks][1] - va[ks][1];
+        }
+        dma_dst = __builtin_amdgcn_readfirstlane(tog - dma_dst);
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> the epilogue's reads (the compiler does not see the MFMAs)
+#undef X3D_SYNC
+#undef X3D_OWN_A
+    } else {
+    // Software pipeline inside the wave (the compiler's own order put each 16-k step's split -- 44 dependent VALU -- and its LDS
+    // round trips IN FRONT of that step's MFMAs: PMC showed the matrix pipe 44 % busy with the waves 48 % of their cycles in issue
+    // stalls).  Here every MFMA group carries, in its shadow, the work of a LATER group: the weight fragments of the next column
+    // block are read into the other register set, and one float pair per column block of the NEXT 16-k step's A piece is split --
+    // the step after the last one of a tile belongs to the next tile, whose A rows this very wave fetched (its own counted wait, no
+    // barrier).  Operand sets are named statically (fa[2], fb[2], raw[2]); the k loop is unrolled by two over the ring slots.
+    constexpr int PJ = 4 / CW;                                 // float pairs of the next step's 8-float piece split per column block
+    static_assert(CW == 2 || CW == 4, "the split is spread over 2 or 4 column blocks");
+    bf16x8 fa[2][NP], fb[2][NP];
+    float4 raw[2][2];                                          // the two 16-byte halves of the A piece of a 16-k step
+    unsigned pl[3][4];
+    auto read_raw = [&](const unsigned char* Ab, int ks, int set) {
+        raw[set][0] = *(const float4*)(Ab + fa_off[ks][0]);
+        raw[set][1] = *(const float4*)(Ab + fa_off[ks][1]);
+    };
+    auto split_pair = [&](int set, int q) {                   // float pair q (0..3) of raw[set] -> pl[.][q]
+        const float4 v = raw[set][q >> 1];
+        if (q & 1) x3_split2(v.z, v.w, pl[0][q], pl[1][q], pl[2][q]);
+        else x3_split2(v.x, v.y, pl[0][q], pl[1][q], pl[2][q]);
+    };
+    auto pack_fa = [&](int set) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) fa[set][p] = __builtin_bit_cast(bf16x8, make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]));
+    };
+    auto read_fb = [&](const unsigned char* Bb, int ks, int jj, int set) {
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+            fb[set][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + (p * BN + jj * 32) * XROW + f_off[ks]));
+    };
+    // one 16-k step: MFMAs of (fa[fs], all column blocks) from ring slot `Bb`; in their shadow the fragments of the next block
+    // (the first block of the following step -- `Bn`, step `ksn` -- at the end) and the split of raw[fs ^ 1] -> fa[fs ^ 1]
+    auto step = [&](const unsigned char* Bb, int ks, int fs, const unsigned char* Bn, int ksn, bool have_next) {
+#pragma unroll
+        for (int jj = 0; jj < CW; jj++) {
+            const int cs = jj & 1;
+            if (jj + 1 < CW) read_fb(Bb, ks, jj + 1, cs ^ 1);
+            else if (have_next) read_fb(Bn, ksn, 0, cs ^ 1);
+#define X3D_TERM(PA, PB) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][PA], fb[cs][PB], acc[jj], 0, 0, 0);
+            if (NP == 3) { X3D_TERM(2, 0) X3D_TERM(1, 1) X3D_TERM(0, 2) }
+            if (NP >= 2) { X3D_TERM((NP >= 2 ? 1 : 0), 0) X3D_TERM(0, (NP >= 2 ? 1 : 0)) }
+            X3D_TERM(0, 0)
+#undef X3D_TERM
+#pragma unroll
+            for (int q = 0; q < PJ; q++) split_pair(fs ^ 1, jj * PJ + q);
+            // pin the interleave: every MFMA (32 cycles of matrix pipe) carries one fragment read and two to four split instructions
+#pragma unroll
+            for (int m = 0; m < 2 * NP; m++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (m < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2 * PJ, 0);
+            }
+        }
+        pack_fa(fs ^ 1);
+    };
+    const unsigned char* S0 = &sm[0];
+    const unsigned char* S1 = &sm[A_BYTES + B_BYTES];
+#define X3D_SYNC() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+#define X3D_OWN_A() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQ) : "memory")      // this wave's A rows of the next tile have landed (issued before the weights)
+    dma_tile(0, 0);
+    X3D_SYNC();
+    // pipeline prologue: fa[0] = step 0 of tile 0, raw[1] = step 1, fb[0] = (step 0, block 0)
+    read_raw(S0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) split_pair(0, q);
+    pack_fa(0);
+    read_raw(S0, 1, 1);
+    read_fb(S0 + A_BYTES, 0, 0, 0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // ---- tile kt in slot 0; tile kt + 1 streams into slot 1
+        if (kt + 1 < nk) dma_tile(kt + 1, 1);
+        step(S0 + A_BYTES, 0, 0, S0 + A_BYTES, 1, true);
+        X3D_OWN_A();
+        read_raw(S1, 0, 0);                                    // (stale data after the last tile: split, never used)
+        step(S0 + A_BYTES, 1, 1, S1 + A_BYTES, 0, false);
+        read_raw(S1, 1, 1);
+        X3D_SYNC();                                            // tile kt + 1 has landed everywhere; slot 0 is free
+        if (kt + 1 >= nk) break;
+        read_fb(S1 + A_BYTES, 0, 0, 0);
+        // ---- tile kt + 1 in slot 1; tile kt + 2 streams into slot 0
+        if (kt + 2 < nk) dma_tile(kt + 2, 0);
+        step(S1 + A_BYTES, 0, 0, S1 + A_BYTES, 1, true);
+        X3D_OWN_A();
+        read_raw(S0, 0, 0);
+        step(S1 + A_BYTES, 1, 1, S0 + A_BYTES, 0, false);
+        read_raw(S0, 1, 1);
+        X3D_SYNC();
+        read_fb(S0 + A_BYTES, 0, 0, 0);
+    }
+#undef X3D_SYNC
+#undef X3D_OWN_A
+
+    }
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
+    // SOUT: the finished values also go to an LDS image of the tile (row-major, BN floats per row: a store instruction covers 2 x 32
+    // consecutive floats -- conflict free), from which the per-cloud column sums are taken once the accumulators are dead: doing the
+    // float64 sums on the live accumulators put every statistics variant at the 256-register cliff (the CW = 2 one spilled around the
+    // asm loop and broke it).
+    float* T = (float*)&sm[0];                             // [BM][BN], free after the k loop's last barrier
+#pragma unroll
+    for (int j = 0; j < CW; j++) {
+        const int col = n0 + j * 32 + l31;
+        const int rloc = wave * 32 + 4 * hi;
+        if (g.partial) {   // split-K: raw accumulators, epilogue happens in k_x3_splitk_reduce
+            float* P = g.partial + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + rloc + (r & 3) + 8 * (r >> 2);
+                if (row < g.M) P[(size_t)row * g.N + col] = acc[j][r];
+            }
+            continue;
+        }
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rl = rloc + (r & 3) + 8 * (r >> 2), row = m0 + rl;
+            float v = 0.f;
+            if (row < g.M) {
+                v = acc[j][r];
+                if (g.row_div) v = v / g.row_div[row];
+                v += bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                g.C[(size_t)row * g.ldc + col] = v;
+            }
+            if (SOUT) T[rl * BN + j * 32 + l31] = v;
+        }
+    }
+    if constexpr (SOUT) {
+        // per cloud s owning rows of this tile: per-column (sum, sum of squares) in float64 over the tile's rows of s ->
+        // stat_partial[(tile_m + s) * N + col] (slot tile_m + s is unique: both only grow along M); regtr_instnorm_finalize_tiles adds
+        // the slots of a cloud in fixed order.  256 threads = PARTS row classes x BN columns, fixed order everywhere: deterministic.
+        constexpr int PARTS = 256 / BN;
+        static_assert(BM * BN * 4 + PARTS * BN * sizeof(double2) <= 2 * (A_BYTES + B_BYTES), "tile image + partial sums must fit the operand ring");
+        double2* red = (double2*)&sm[BM * BN * 4];
+        const int c = t % BN, part = t / BN;
+        __syncthreads();
+        for (int sg = s_lo; sg <= s_hi; sg++) {            // workgroup-uniform; one cloud per tile almost always
+            const int r_lo = max((sg == s_lo ? s_lo_begin : g.stat_seg_off[sg]) - m0, 0);
+            const int r_hi = min(min(sg == s_lo ? s_lo_end : g.stat_seg_off[sg + 1], g.M) - m0, BM);
+            double sm_ = 0.0, sq = 0.0;
+            for (int r = r_lo + part; r < r_hi; r += PARTS) { const double v = (double)T[r * BN + c]; sm_ += v; sq += v * v; }
+            red[part * BN + c] = make_double2(sm_, sq);
+            __syncthreads();
+            if (t < BN) {
+                double2 a = red[t];
+#pragma unroll
+                for (int w = 1; w < PARTS; w++) { const double2 b = red[w * BN + t]; a.x += b.x; a.y += b.y; }
+                g.stat_partial[(size_t)(tile_m + sg) * g.N + n0 + t] = a;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -380,14 +796,24 @@ __global__ void __launch_bounds__(256) k_tile_segments(const int* __restrict__ s
     out[t] = make_int4(lo, hi, seg_off[lo], seg_off[lo + 1]);
 }
 
-struct X3Plan { int tile, splits, k_chunk; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64
+struct X3Plan { int tile, splits, k_chunk; bool strip; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64; strip: the row-strip kernel
 
 // tile shape and K split for a problem (host policy)
 X3Plan x3_plan(int M, int N, int K)
 {
-    X3Plan p{2, 1, K};
+    X3Plan p{2, 1, K, false};
+    static const int strip_on = (getenv("REGTR_X3_STRIP") && *getenv("REGTR_X3_STRIP")) ? atoi(getenv("REGTR_X3_STRIP")) : 1;   // development: A/B runs
     static const int forced = (getenv("REGTR_X3_TILE") && *getenv("REGTR_X3_TILE")) ? atoi(getenv("REGTR_X3_TILE")) : -1;   // development: tile A/B runs
-    if (forced >= 0 && forced <= 2 && (forced != 0 || N % 128 == 0)) { p.tile = forced; return p; }
+    static const int forced_s = (getenv("REGTR_X3_SPLITS") && *getenv("REGTR_X3_SPLITS")) ? atoi(getenv("REGTR_X3_SPLITS")) : 0;   // development
+    if (forced >= 0 && forced <= 2 && (forced != 0 || N % 128 == 0)) {
+        p.tile = forced;
+        p.strip = strip_on && p.tile != 2;
+        if (forced_s >= 2 && K / forced_s >= 64) {
+            p.k_chunk = rg_cdiv(rg_cdiv(K, forced_s), XBK) * XBK;
+            p.splits = rg_cdiv(K, p.k_chunk);
+        }
+        return p;
+    }
     auto tiles = [&](int bm, int bn) { return (long long)rg_cdiv(M, bm) * (N / bn); };
     // Measured on MI355X (REGTR_X3_TILE = 0 / 1 / 2 sweeps over RegTR's shapes at 16 and 64 pairs per forward): with a few
     // hundred tiles the 64 x 64 tile at four workgroups per CU wins (occupancy hides the per-k-tile latency); from about
@@ -407,6 +833,7 @@ X3Plan x3_plan(int M, int N, int K)
             p.splits = rg_cdiv(K, p.k_chunk);
         }
     }
+    p.strip = strip_on && p.tile != 2;
     return p;
 }
 
@@ -509,10 +936,19 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
                        else k_gemm_x3<MW_, NW_, WM_, WN_, true, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \
         else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)
-    if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);          // 128 x 128, 8 waves of 64 x 32
+#define X3D_LAUNCH(CW_) do { \
+        if (n_planes == 1) k_gemm_x3d<CW_, false, 1><<<grid, 256, 0, st>>>(g); \
+        else if (n_planes == 2) k_gemm_x3d<CW_, false, 2><<<grid, 256, 0, st>>>(g); \
+        else if (stat_partial) k_gemm_x3d<CW_, true><<<grid, 256, 0, st>>>(g); \
+        else k_gemm_x3d<CW_, false><<<grid, 256, 0, st>>>(g); } while (0)
+    const bool strip = p.strip && !a_stats && K % XBK == 0 && p.k_chunk % XBK == 0;
+    if (strip && p.tile == 0) X3D_LAUNCH(4);         // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
+    else if (strip) X3D_LAUNCH(2);                   // 128 x 64
+    else if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);     // 128 x 128, 8 waves of 64 x 32
     else if (p.tile == 1) X3_LAUNCH(2, 2, 2, 1);     // 128 x 64, 4 waves of 64 x 32
     else X3_LAUNCH(2, 2, 1, 1);                      // 64 x 64, 4 waves of 32 x 32
 #undef X3_LAUNCH
+#undef X3D_LAUNCH
     if (p.splits > 1) k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

@@ -38,3 +38,37 @@ def test_lomatch_set_is_sharded_and_gathered_every_pass():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert d['n_gpus'] == 2 and d['pairs_per_step'] == 23 and d['forwards_per_step_rank0'] == 3 and d['scaling'] == 'strong'
+
+
+def test_parity_check_logic_on_cpu():
+    """bench.parity_check (the "pose err vs ref" field of the bench line) on a stand-in product: the oracle's own batched forward must
+    pass with zero error, a 1e-3 shift of one correspondence row must fail the gate, a broken key point must fail bit-exactness."""
+    import sys
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import regtr_ref
+    from regtr_amd.synthetic import synth_pair
+    from tests.util import load_cfg, seeded_sd
+    cfg = load_cfg('3dmatch')
+    sd = seeded_sd(cfg)
+
+    class Model:
+        def state_dict(self):
+            return sd
+    pairs = [synth_pair(i, 2500) for i in range(2)]
+    with torch.no_grad():
+        out = regtr_ref.regtr_forward(sd, cfg, [s for s, _ in pairs], [t for _, t in pairs])
+    par = bench.parity_check(cfg, Model(), pairs, out, [0, 1])
+    assert par['ok'] and par['keypoints_bit_exact'] and par['corr_max_abs'] < 1e-5 and par['pose_max_abs'] < 1e-4 and par['pairs_checked'] == 2, par
+    assert par['kabsch_cond_max'] > 1.0 and par['pose_vs_f64_kabsch_of_own_outputs'] < 1e-4
+    bad = dict(out)
+    bad['src_kp_warped'] = [c.clone() for c in out['src_kp_warped']]
+    bad['src_kp_warped'][1][:, 0] += 1e-3
+    assert not bench.parity_check(cfg, Model(), pairs, bad, [0, 1])['ok']
+    bad = dict(out)
+    bad['tgt_kp'] = [k.clone() for k in out['tgt_kp']]
+    bad['tgt_kp'][0][3, 1] += 1e-6
+    r = bench.parity_check(cfg, Model(), pairs, bad, [0, 1])
+    assert not r['ok'] and not r['keypoints_bit_exact']

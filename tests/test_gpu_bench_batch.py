@@ -61,7 +61,7 @@ def test_bench_batch_tables_and_outputs_vs_oracle():
     assert max(worst.values()) < 1e-4, worst
     # and bench.py's own parity field says the same thing about the same outputs
     par = bench.parity_check(cfg, model, pairs, out, [0, len(pairs) - 1])
-    assert par['ok'] and par['keypoints_bit_exact'] and par['pose_max_abs'] < 1e-4 and par['pairs_checked'] == 2, par
+    assert par["ok"] and par["keypoints_bit_exact"] and par["corr_max_abs"] < 1e-4 and par["pairs_checked"] == 2, par
 
 
 def test_lomatch_pairs_vs_oracle_and_ragged_forward():

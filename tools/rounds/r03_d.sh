@@ -1,0 +1,5 @@
+#!/bin/bash
+out=gpurun_out/r03_d; mkdir -p $out; export TMPDIR=/tmp
+timeout 1200 python tools/x3_bench.py --arms "tiled=REGTR_X3_STRIP:0" "strip=REGTR_X3_PIPE:0" "pipe=REGTR_X3_PIPE:1" "pipe_t1=REGTR_X3_PIPE:1,REGTR_X3_TILE:1" "pipe_p1=X3_PLANES:1" > $out/x3_pipe.md 2>&1
+cat $out/x3_pipe.md
+timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -x -q -k "gemm or split or x3 or unary or kpconv" > $out/pytest_gemm.log 2>&1; tail -3 $out/pytest_gemm.log
