@@ -416,15 +416,20 @@ __device__ __forceinline__ void x3h_split_b(float ra, float rb, unsigned& p1, un
 #define X3D_HAND 1       // development (REGTR_VARIANT_FLAGS=-DX3D_HAND=0): the compiler-scheduled k loop for A/B runs
 #endif
 
-template <int CW, bool SOUT, int NP = 3>
-__global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
+// MW waves (4 or 8: 128- or 256-row tiles; the weight tile is shared by all of them, so twice the rows halve the weight traffic per
+// MFMA), CW 32-column blocks per wave, AR slots of the wave-private A ring (3: the A rows of tile t + 2 are in flight while tile t is
+// multiplied -- a full tile more than the weights get, which hit L2 while A comes from HBM), NP planes.
+template <int MW, int CW, int AR, bool SOUT, int NP = 3>
+__global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
 {
-    constexpr int MW = 4, BM = 32 * MW, BN = 32 * CW;
-    constexpr int A_BYTES = BM * XBK * 4;                      // raw float32 rows of one k-tile: 16 KiB
+    constexpr int NT = 64 * MW, BM = 32 * MW, BN = 32 * CW;
+    constexpr int A_BYTES = BM * XBK * 4;                      // raw float32 rows of one k-tile: 128 bytes per row
     constexpr int B_BYTES = NP * BN * XROW;
-    constexpr int NQ = B_BYTES / 1024 / MW, NA = A_BYTES / 1024 / MW;
-    static_assert(NQ * 1024 * MW == B_BYTES && NA == 4, "operand tiles must split evenly over the waves");
-    __shared__ __align__(1024) unsigned char sm[2 * (A_BYTES + B_BYTES)];
+    constexpr int NQ = B_BYTES / 1024 / MW, NA = 4;            // LDS-DMA instructions (1 KiB) per wave and k-tile: weights / own A rows
+    constexpr int A_RING = AR * A_BYTES, LDS_BYTES = A_RING + 2 * B_BYTES;
+    static_assert(NQ * 1024 * MW == B_BYTES && NQ >= 1, "the weight tile must split evenly over the waves");
+    static_assert(AR == 2 || AR == 3, "A ring depth");
+    __shared__ __align__(1024) unsigned char sm[LDS_BYTES];   // [A ring: AR x BM rows x 128 B][weight ring: 2 x NP planes x BN x 64 B]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -468,12 +473,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
         b_src[q] = g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + kc * 8 + k_begin;
     }
     const unsigned lds_base = (unsigned)(unsigned long long)(x3_lds_ptr)(&sm[0]);
-    auto dma_tile = [&](int kt, int buf) {                    // operands of k-tile kt -> ring slot buf; A first: the wave reads its own rows early
-        const unsigned bb = lds_base + (unsigned)buf * (A_BYTES + B_BYTES);
+    const unsigned a_wave = lds_base + (unsigned)wave * (NA * 1024u);             // this wave's 4 KiB of an A slot
+    const unsigned b_wave = lds_base + A_RING + (unsigned)wave * (NQ * 1024u);    // this wave's share of a weight slot
+    auto dma_a = [&](int kt, unsigned slot) {                  // own A rows of k-tile kt -> A slot
 #pragma unroll
-        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), bb + (unsigned)(wave * NA + q) * 1024u);
+        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), a_wave + slot * A_BYTES + q * 1024u);
+    };
+    auto dma_b = [&](int kt, unsigned slot) {                  // this wave's share of the weight planes of k-tile kt -> weight slot
 #pragma unroll
-        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), bb + A_BYTES + (unsigned)(wave * NQ + q) * 1024u);
+        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), b_wave + slot * B_BYTES + q * 1024u);
     };
     // fragment addresses: A row 32 wave + l31, 16-byte chunks 4 ks + 2 hi (+ 1), swizzled; B as in k_gemm_x3
     unsigned fa_off[2][2], f_off[2];
@@ -496,21 +504,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
     // ---- hand-scheduled k loop.  Per 16-k step and column block: three fragment reads of the NEXT block are issued, the wait
     // leaves exactly those in flight, then the block's six MFMAs go out with the two halves of one float pair's split (of the next
     // step's A piece) behind the first two.  Register sets are static -- fa[2] (step parity), fb[2] (block parity), raw[2] -- and
-    // the ring slot is carried in the ADDRESS registers (toggled by one subtraction per tile), so the loop body is one tile and no
-    // accumulator is ever copied between differently-allocated halves of an unrolled loop.
-    constexpr int SLOT = A_BYTES + B_BYTES;
+    // the ring slots are carried in the ADDRESS registers, so the loop body is one tile and no accumulator is ever copied between
+    // differently-allocated halves of an unrolled loop.
+    // Operand streams per tile t (all LDS-DMA, issued from asm, counted by hand; one in-order counter):
+    //   AR = 2:  top: A(t+1) then W(t+1)            mid-tile: vmcnt(NQ) = A(t+1) landed        end: vmcnt(0) + barrier
+    //   AR = 3:  top: W(t+1) then A(t+2)            mid-tile: vmcnt(NQ + 4) = A(t+1) landed    end: vmcnt(4) + barrier (A(t+2) stays in flight)
     constexpr int PJ = 4 / CW;
     static_assert(CW == 2 || CW == 4, "the split is spread over 2 or 4 column blocks");
-    // per-lane LDS byte addresses: weights of the CURRENT slot at step ks; A piece halves of the NEXT slot
-    unsigned vb[2], va[2][2];
+    unsigned vb[2], va[2][2];              // per-lane LDS addresses: weights of the CURRENT slot at step ks; A piece halves of the NEXT tile's slot
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
-        vb[ks] = lds_base + A_BYTES + f_off[ks];
-        va[ks][0] = lds_base + SLOT + fa_off[ks][0];
-        va[ks][1] = lds_base + SLOT + fa_off[ks][1];
+        vb[ks] = lds_base + A_RING + f_off[ks];
+        va[ks][0] = lds_base + A_BYTES + fa_off[ks][0];
+        va[ks][1] = lds_base + A_BYTES + fa_off[ks][1];
     }
-    unsigned dma_dst = lds_base + SLOT;                         // ring slot the next tile streams into (wave-uniform)
-    const unsigned tog = 2u * lds_base + SLOT;                  // slot address toggle: x -> tog + 2 (x's offset within a slot) - x
+    unsigned b_slot = 1, a_slot = AR - 1, a_read = 1;           // (wave-uniform) weight slot / A slot the next DMAs go to; A slot read next
     uint4 fbq[2][3], rawq[2][2];          // weight fragments (block parity, plane); A piece halves (step parity, half)
     unsigned pl[2][3][4];                  // split planes being built (step parity, plane, float pair)
     bf16x8 fa[2][3];
@@ -559,17 +567,14 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
             X3H_LGKM(0); X3H_BLOCK(1, FS, 1); \
         } \
         X3H_PACK((FS) ^ 1); } while (0)
-#define X3D_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#define X3D_OWN_A() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQ) : "memory")
-    auto dma_next = [&](int kt) {                              // operands of k-tile kt -> the slot at dma_dst; A first (read early by this wave)
-#pragma unroll
-        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), dma_dst + (unsigned)(wave * NA + q) * 1024u);
-#pragma unroll
-        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), dma_dst + A_BYTES + (unsigned)(wave * NQ + q) * 1024u);
-    };
-    dma_tile(0, 0);
-    X3D_SYNC();
-    // pipeline prologue: fa[0] = step 0 of tile 0 (split here, unhidden, once), raw[1] = step 1's piece -- both from slot 0
+#define X3H_VM(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
+#define X3H_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // prologue: weights and A of tile 0 (and, with the deeper ring, A of tile 1)
+    dma_b(0, 0);
+    dma_a(0, 0);
+    if (AR == 3 && nk > 1) { dma_a(1, 1); X3H_VM(4); } else X3H_VM(0);
+    X3H_BARRIER();
+    // fa[0] = step 0 of tile 0 (split here, unhidden, once), raw[1] = step 1's piece -- both from A slot 0
     {
         unsigned a00 = lds_base + fa_off[0][0], a01 = lds_base + fa_off[0][1], a10 = lds_base + fa_off[1][0], a11 = lds_base + fa_off[1][1];
         x3h_lds128<0>(rawq[0][0], a00); x3h_lds128<0>(rawq[0][1], a01);
@@ -579,35 +584,55 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
 #pragma unroll
     for (int q = 0; q < 4; q++) { X3H_PAIR_A(0, q); X3H_PAIR_B(0, q); }
     X3H_PACK(0);
+#ifdef X3D_PROF          // development: per-wave phase clocks of three workgroups (REGTR_VARIANT_FLAGS=-DX3D_PROF)
+    long long pt[5] = {0, 0, 0, 0, 0}, pc = clock64();
+#define X3D_STAMP(I) do { const long long n_ = clock64(); pt[I] += n_ - pc; pc = n_; } while (0)
+#else
+#define X3D_STAMP(I) do {} while (0)
+#endif
     for (int kt = 0; kt < nk; kt++) {
-        if (kt + 1 < nk) dma_next(kt + 1);
+        const bool more_b = kt + 1 < nk, more_a = kt + AR - 1 < nk;             // wave-uniform
+        if (AR == 2) { if (more_a) dma_a(kt + 1, a_slot); if (more_b) dma_b(kt + 1, b_slot); }
+        else         { if (more_b) dma_b(kt + 1, b_slot); if (more_a) dma_a(kt + 2, a_slot); }
+        X3D_STAMP(0);
         X3H_FB(0, 0, 0);
         X3H_STEP_MID(0, 0, 1);
-        X3D_OWN_A();                                           // this wave's A rows of tile kt + 1 (stale data after the last tile)
+        X3D_STAMP(1);
+        // this wave's A rows of tile kt + 1 have landed (after the last tile: stale data, split and never used)
+        if (AR == 2) { if (more_b) X3H_VM(NQ); else X3H_VM(0); }
+        else { if (more_b && more_a) X3H_VM(NQ + 4); else if (more_b) X3H_VM(NQ); else X3H_VM(0); }
+        X3D_STAMP(2);
         X3H_RAW(0, 0);
         X3H_RAW(1, 1);
         X3H_STEP_END(1, 1);
-        X3D_SYNC();                                            // tile kt + 1 has landed everywhere; the current slot is free
-        // swap the ring slots: weights of the current slot <-> A pieces / DMA target of the next
+        X3D_STAMP(3);
+        if (AR == 3 && more_a) X3H_VM(4); else X3H_VM(0);       // the weights of tile kt + 1 have landed (A of tile kt + 2 stays in flight)
+        X3H_BARRIER();                                          // ... everywhere; the current weight slot is free
+        X3D_STAMP(4);
+        // advance the rings: weights of the slot just filled; A pieces of the slot after the one just read; DMA targets
+        {
+            const unsigned nb = b_slot;
+            b_slot ^= 1u;
+            a_read = a_read + 1 == AR ? 0 : a_read + 1;
+            a_slot = a_slot + 1 == AR ? 0 : a_slot + 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
-            vb[ks] = tog + 2u * (A_BYTES + f_off[ks]) - vb[ks];
-            va[ks][0] = tog + 2u * fa_off[ks][0] - va[ks][0];
-            va[ks][1] = tog + 2u * fa_off[ks][1] - va[ks][1];
+            for (int ks = 0; ks < 2; ks++) {
+                vb[ks] = lds_base + A_RING + nb * B_BYTES + f_off[ks];
+                va[ks][0] = lds_base + a_read * A_BYTES + fa_off[ks][0];
+                va[ks][1] = lds_base + a_read * A_BYTES + fa_off[ks][1];
+            }
         }
-        dma_dst = __builtin_amdgcn_readfirstlane(tog - dma_dst);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> the epilogue's reads (the compiler does not see the MFMAs)
-#undef X3D_SYNC
-#undef X3D_OWN_A
+#ifdef X3D_PROF
+    if ((blockIdx.x == 0 || blockIdx.x == 301 || blockIdx.x == gridDim.x - 9) && lane == 0)
+        printf("x3d M %d N %d K %d MW %d CW %d AR %d blk %d wave %d nk %d: dma-issue %lld step0 %lld own-A-wait %lld step1 %lld sync %lld (cycles)\n", g.M, g.N, g.K,
+               MW, CW, AR, (int)blockIdx.x, wave, nk, pt[0], pt[1], pt[2], pt[3], pt[4]);
+#endif
     } else {
-    // Software pipeline inside the wave (the compiler's own order put each 16-k step's split -- 44 dependent VALU -- and its LDS
-    // round trips IN FRONT of that step's MFMAs: PMC showed the matrix pipe 44 % busy with the waves 48 % of their cycles in issue
-    // stalls).  Here every MFMA group carries, in its shadow, the work of a LATER group: the weight fragments of the next column
-    // block are read into the other register set, and one float pair per column block of the NEXT 16-k step's A piece is split --
-    // the step after the last one of a tile belongs to the next tile, whose A rows this very wave fetched (its own counted wait, no
-    // barrier).  Operand sets are named statically (fa[2], fb[2], raw[2]); the k loop is unrolled by two over the ring slots.
-    constexpr int PJ = 4 / CW;                                 // float pairs of the next step's 8-float piece split per column block
+    // ---- compiler-scheduled k loop (one / two planes per operand: cfg.compute_dtype 'bf16' / 'bf16x2'; development builds -DX3D_HAND=0)
+    static_assert(AR == 2, "the compiler-scheduled loop uses the two-slot A ring");
+    constexpr int PJ = 4 / CW;
     static_assert(CW == 2 || CW == 4, "the split is spread over 2 or 4 column blocks");
     bf16x8 fa[2][NP], fb[2][NP];
     float4 raw[2][2];                                          // the two 16-byte halves of the A piece of a 16-k step
@@ -630,8 +655,6 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
         for (int p = 0; p < NP; p++)
             fb[set][p] = __builtin_bit_cast(bf16x8, *(const uint4*)(Bb + (p * BN + jj * 32) * XROW + f_off[ks]));
     };
-    // one 16-k step: MFMAs of (fa[fs], all column blocks) from ring slot `Bb`; in their shadow the fragments of the next block
-    // (the first block of the following step -- `Bn`, step `ksn` -- at the end) and the split of raw[fs ^ 1] -> fa[fs ^ 1]
     auto step = [&](const unsigned char* Bb, int ks, int fs, const unsigned char* Bn, int ksn, bool have_next) {
 #pragma unroll
         for (int jj = 0; jj < CW; jj++) {
@@ -645,53 +668,44 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
 #undef X3D_TERM
 #pragma unroll
             for (int q = 0; q < PJ; q++) split_pair(fs ^ 1, jj * PJ + q);
-            // pin the interleave: every MFMA (32 cycles of matrix pipe) carries one fragment read and two to four split instructions
-#pragma unroll
-            for (int m = 0; m < 2 * NP; m++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (m < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 2 * PJ, 0);
-            }
         }
         pack_fa(fs ^ 1);
     };
-    const unsigned char* S0 = &sm[0];
-    const unsigned char* S1 = &sm[A_BYTES + B_BYTES];
+    const unsigned char* A0 = &sm[0];
+    const unsigned char* A1 = &sm[A_BYTES];
+    const unsigned char* B0 = &sm[A_RING];
+    const unsigned char* B1 = &sm[A_RING + B_BYTES];
 #define X3D_SYNC() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
 #define X3D_OWN_A() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NQ) : "memory")      // this wave's A rows of the next tile have landed (issued before the weights)
-    dma_tile(0, 0);
+    dma_a(0, 0); dma_b(0, 0);
     X3D_SYNC();
-    // pipeline prologue: fa[0] = step 0 of tile 0, raw[1] = step 1, fb[0] = (step 0, block 0)
-    read_raw(S0, 0, 0);
+    read_raw(A0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; q++) split_pair(0, q);
     pack_fa(0);
-    read_raw(S0, 1, 1);
-    read_fb(S0 + A_BYTES, 0, 0, 0);
+    read_raw(A0, 1, 1);
+    read_fb(B0, 0, 0, 0);
     for (int kt = 0; kt < nk; kt += 2) {
-        // ---- tile kt in slot 0; tile kt + 1 streams into slot 1
-        if (kt + 1 < nk) dma_tile(kt + 1, 1);
-        step(S0 + A_BYTES, 0, 0, S0 + A_BYTES, 1, true);
+        if (kt + 1 < nk) { dma_a(kt + 1, 1); dma_b(kt + 1, 1); }
+        step(B0, 0, 0, B0, 1, true);
         X3D_OWN_A();
-        read_raw(S1, 0, 0);                                    // (stale data after the last tile: split, never used)
-        step(S0 + A_BYTES, 1, 1, S1 + A_BYTES, 0, false);
-        read_raw(S1, 1, 1);
+        read_raw(A1, 0, 0);                                    // (stale data after the last tile: split, never used)
+        step(B0, 1, 1, B1, 0, false);
+        read_raw(A1, 1, 1);
         X3D_SYNC();                                            // tile kt + 1 has landed everywhere; slot 0 is free
         if (kt + 1 >= nk) break;
-        read_fb(S1 + A_BYTES, 0, 0, 0);
-        // ---- tile kt + 1 in slot 1; tile kt + 2 streams into slot 0
-        if (kt + 2 < nk) dma_tile(kt + 2, 0);
-        step(S1 + A_BYTES, 0, 0, S1 + A_BYTES, 1, true);
+        read_fb(B1, 0, 0, 0);
+        if (kt + 2 < nk) { dma_a(kt + 2, 0); dma_b(kt + 2, 0); }
+        step(B1, 0, 0, B1, 1, true);
         X3D_OWN_A();
-        read_raw(S0, 0, 0);
-        step(S1 + A_BYTES, 1, 1, S0 + A_BYTES, 0, false);
-        read_raw(S0, 1, 1);
+        read_raw(A0, 0, 0);
+        step(B1, 1, 1, B0, 0, false);
+        read_raw(A0, 1, 1);
         X3D_SYNC();
-        read_fb(S0 + A_BYTES, 0, 0, 0);
+        read_fb(B0, 0, 0, 0);
     }
 #undef X3D_SYNC
 #undef X3D_OWN_A
-
     }
 
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
@@ -732,9 +746,9 @@ __global__ void __launch_bounds__(256, 2) k_gemm_x3d(X3Args g)
     if constexpr (SOUT) {
         // per cloud s owning rows of this tile: per-column (sum, sum of squares) in float64 over the tile's rows of s ->
         // stat_partial[(tile_m + s) * N + col] (slot tile_m + s is unique: both only grow along M); regtr_instnorm_finalize_tiles adds
-        // the slots of a cloud in fixed order.  256 threads = PARTS row classes x BN columns, fixed order everywhere: deterministic.
-        constexpr int PARTS = 256 / BN;
-        static_assert(BM * BN * 4 + PARTS * BN * sizeof(double2) <= 2 * (A_BYTES + B_BYTES), "tile image + partial sums must fit the operand ring");
+        // the slots of a cloud in fixed order.  NT threads = PARTS row classes x BN columns, fixed order everywhere: deterministic.
+        constexpr int PARTS = NT / BN;
+        static_assert(BM * BN * 4 + PARTS * BN * sizeof(double2) <= LDS_BYTES, "tile image + partial sums must fit the operand rings");
         double2* red = (double2*)&sm[BM * BN * 4];
         const int c = t % BN, part = t / BN;
         __syncthreads();
@@ -796,7 +810,7 @@ __global__ void __launch_bounds__(256) k_tile_segments(const int* __restrict__ s
     out[t] = make_int4(lo, hi, seg_off[lo], seg_off[lo + 1]);
 }
 
-struct X3Plan { int tile, splits, k_chunk; bool strip; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64; strip: the row-strip kernel
+struct X3Plan { int tile, splits, k_chunk; bool strip; };      // tile: 0 = 128 x 128, 1 = 128 x 64, 2 = 64 x 64; strip: the row-strip kernel where eligible
 
 // tile shape and K split for a problem (host policy)
 X3Plan x3_plan(int M, int N, int K)
@@ -822,6 +836,8 @@ X3Plan x3_plan(int M, int N, int K)
     p.tile = 2;
     if (tiles(128, 64) >= 512 && (K >= 960 || tiles(128, 64) >= 2048)) p.tile = 1;
     if (N % 128 == 0 && tiles(128, 128) >= 1536) p.tile = 0;
+    // deep K on the row-strip kernel: the 128-column tile reads A half as often (level-2 / level-3 KPConv contractions: 483 vs 511, 478 vs 481 us)
+    if (strip_on && N % 128 == 0 && K >= 1536 && K % XBK == 0 && tiles(128, 128) >= 512) p.tile = 0;
     const long long tl = p.tile == 0 ? tiles(128, 128) : (p.tile == 1 ? tiles(128, 64) : tiles(64, 64));
     if (tl < 384 && K >= 512) {
         int s = (int)((768 + tl - 1) / tl);
@@ -936,14 +952,19 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
                        else k_gemm_x3<MW_, NW_, WM_, WN_, true, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \
         else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)
-#define X3D_LAUNCH(CW_) do { \
-        if (n_planes == 1) k_gemm_x3d<CW_, false, 1><<<grid, 256, 0, st>>>(g); \
-        else if (n_planes == 2) k_gemm_x3d<CW_, false, 2><<<grid, 256, 0, st>>>(g); \
-        else if (stat_partial) k_gemm_x3d<CW_, true><<<grid, 256, 0, st>>>(g); \
-        else k_gemm_x3d<CW_, false><<<grid, 256, 0, st>>>(g); } while (0)
+#define X3D_LAUNCH(MW_, CW_, AR_) do { \
+        if (n_planes == 1) k_gemm_x3d<4, CW_, 2, false, 1><<<grid, 256, 0, st>>>(g); \
+        else if (n_planes == 2) k_gemm_x3d<4, CW_, 2, false, 2><<<grid, 256, 0, st>>>(g); \
+        else if (stat_partial) k_gemm_x3d<MW_, CW_, AR_, true><<<grid, 64 * MW_, 0, st>>>(g); \
+        else k_gemm_x3d<MW_, CW_, AR_, false><<<grid, 64 * MW_, 0, st>>>(g); } while (0)
     const bool strip = p.strip && !a_stats && K % XBK == 0 && p.k_chunk % XBK == 0;
-    if (strip && p.tile == 0) X3D_LAUNCH(4);         // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
-    else if (strip) X3D_LAUNCH(2);                   // 128 x 64
+    static const int a_ring = (getenv("REGTR_X3_ARING") && *getenv("REGTR_X3_ARING")) ? atoi(getenv("REGTR_X3_ARING")) : 3;   // development: A/B runs
+    // (measured and left out: 8 waves on 256 x 128 tiles, 144 KiB of LDS, one workgroup per CU -- k_gemm_x3d<8, 4, 3> -- halves the
+    // weight traffic per MFMA and is no faster: 498 vs 483 us on the level-2 contraction, 555 vs 478 at level 3 where 296 tiles
+    // quantise badly over 256 CUs)
+    if (strip && p.tile == 0) X3D_LAUNCH(4, 4, 2);                   // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
+    else if (strip && a_ring == 3) X3D_LAUNCH(4, 2, 3);              // 128 x 64, A rows two tiles ahead
+    else if (strip) X3D_LAUNCH(4, 2, 2);                             // 128 x 64
     else if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);     // 128 x 128, 8 waves of 64 x 32
     else if (p.tile == 1) X3_LAUNCH(2, 2, 2, 1);     // 128 x 64, 4 waves of 64 x 32
     else X3_LAUNCH(2, 2, 1, 1);                      // 64 x 64, 4 waves of 32 x 32
