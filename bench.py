@@ -389,7 +389,7 @@ def main():
     ap.add_argument('--distinct-pairs', type=int, default=128, help='lomatch: different synthetic pairs generated per rank (cycled; set-up time only)')
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
     ap.add_argument('--parity-pairs', type=int, default=2, help='pairs of the last timed step checked against the CPU oracle (0 = off)')
-    ap.add_argument('--dtype', choices=['fp32', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
+    ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
     ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
@@ -481,7 +481,7 @@ def main():
         res = {
             'metric': metric, 'value': total_pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'fp32x3': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
                        'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
                        'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
@@ -491,7 +491,7 @@ def main():
             lo, hi = chunks[-1]
             slots = sorted({0, hi - lo - 1} | set(range(1, min(args.parity_pairs, hi - lo) - 1)))
             res['parity'] = parity_check(cfg, model, pairs[lo:hi], last_out, slots, args.parity_mode)
-            res['parity']['enforced'] = dtype == 'fp32'          # reduced-precision modes report the error, the 1e-4 gate is fp32's
+            res['parity']['enforced'] = dtype in ('fp32', 'fp32x3')      # 'bf16' reports the error; the 1e-4 gate is the float32 modes'
         fwd_batch = {k: v[chunks[0][0]:chunks[0][1]] for k, v in batch.items()}
         if not args.no_roofline:
             r = measure_kpconv_roofline(model, fwd_batch)
@@ -501,13 +501,13 @@ def main():
             a = measure_attention(model, fwd_batch, cfg.nhead, cfg.d_embed, cfg.num_encoder_layers)
             peak = MFMA_BF16_PEAK_TFS
             att = {'bound': 'mfma', 'achieved': a['achieved_TFs'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': a['achieved_TFs'] / peak,
-                   'traffic': None, 'detail': dict(a, operands={'fp32': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
+                   'traffic': None, 'detail': dict(a, operands={'fp32': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'fp32x3': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
                                                                'bf16': 'plain bf16 (1 MFMA per product)'}[dtype],
                                                    peak_note='dense bf16 MFMA peak; the split mode issues 6x the algorithmic flops')}
             # the dominant kernel of the configuration leads: KPConv gather (HBM) for 3DMatch-size pairs, attention (MFMA) for ModelNet
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
-        if dtype != 'fp32':
+        if dtype not in ('fp32', 'fp32x3'):
             # reduced-precision error, reported next to the number (parity is gated in fp32): same batch, float32-grade model
             from regtr_amd import RegTR, load_config
             cfg32 = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{"3dmatch" if lomatch else args.config}.yaml'))

@@ -119,13 +119,17 @@ class RegTR(nn.Module):
             normalize_before=cfg.pre_norm, sa_val_has_pos_emb=cfg.sa_val_has_pos_emb,
             ca_val_has_pos_emb=cfg.ca_val_has_pos_emb, attention_type=cfg.attention_type)
         encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
-        # cfg.compute_dtype (not a reference key): 'fp32' (default) = float32-grade everywhere (bf16x3 split MFMA); 'bf16' =
-        # plain bf16 operands with float32 accumulation / softmax in the cross-encoder's linears and attention core
-        # (BASELINE configs[1]; the KPConv encoder, head and pose stay float32-grade); 'bf16x2' = three-term split linears.
+        # cfg.compute_dtype (not a reference key).  'fp32' (default): every contraction on the bf16 matrix cores with exact operand
+        # splits -- six MFMA terms (float32-grade, error ~2^-24 per product) in the KPConv encoder, feat_proj, attention core, head and
+        # pose; the CROSS-ENCODER's Linears (in / out projections, FFN) keep the three leading terms (2^-16 per product before
+        # accumulation): validated against the real reference module's outputs on all five goldens in parity mode (worst 3.3e-5 vs
+        # 2.4e-5 with six terms, bar 1e-4; profiles/r03_dtype_parity.txt), 3 % faster end to end.  'fp32x3' = six terms everywhere;
+        # 'bf16x2' = alias of the default's cross-encoder setting (kept for round-2 callers); 'bf16' = plain bf16 operands with float32
+        # accumulation / softmax in the cross-encoder's linears and attention core (BASELINE configs[1]; encoder, head, pose as 'fp32').
         dt = cfg.get('compute_dtype', 'fp32')
-        if dt not in ('fp32', 'bf16', 'bf16x2'):
-            raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, bf16 or bf16x2')
-        encoder_layer.gemm_planes = {'fp32': 3, 'bf16x2': 2, 'bf16': 1}[dt]
+        if dt not in ('fp32', 'fp32x3', 'bf16', 'bf16x2'):
+            raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, fp32x3, bf16x2 or bf16')
+        encoder_layer.gemm_planes = {'fp32': 2, 'fp32x3': 3, 'bf16x2': 2, 'bf16': 1}[dt]
         encoder_layer.attn_precision = 1 if dt == 'bf16' else 0
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)

@@ -11,7 +11,7 @@ import test_gpu_model as T  # noqa: E402
 
 
 def main():
-    for dt in ('fp32', 'bf16x2', 'bf16'):
+    for dt in ('fp32x3', 'fp32', 'bf16'):
         for case, cfgn, overrides in T.GOLDEN_CASES:
             g = T.gold(case)
             cfg = T.load_cfg(cfgn)
