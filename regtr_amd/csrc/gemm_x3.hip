@@ -435,8 +435,8 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     const int l31 = lane & 31, hi = lane >> 5;
     int tile_m, tile_n;
     {
-        const int nc = g.N / BN, b = blockIdx.x, x = b & 7, q = b >> 3;       // XCD-aware map, as in k_gemm_x3
-        tile_n = q % nc;
+        const int nc = (g.N + BN - 1) / BN, b = blockIdx.x, x = b & 7, q = b >> 3;       // XCD-aware map, as in k_gemm_x3
+        tile_n = q % nc;                                       // (N = 32: one 64-column tile whose upper half multiplies the planes' zero padding)
         tile_m = (q / nc) * 8 + x;
         if (tile_m * BM >= g.M) return;
     }
@@ -718,6 +718,7 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     for (int j = 0; j < CW; j++) {
         const int col = n0 + j * 32 + l31;
         const int rloc = wave * 32 + 4 * hi;
+        if (n0 + j * 32 >= g.N) continue;                  // (wave-uniform) column block beyond N: the thin N = 32 case
         if (g.partial) {   // split-K: raw accumulators, epilogue happens in k_x3_splitk_reduce
             float* P = g.partial + (size_t)blockIdx.z * g.M * g.N;
 #pragma unroll
@@ -756,10 +757,11 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
             const int r_lo = max((sg == s_lo ? s_lo_begin : g.stat_seg_off[sg]) - m0, 0);
             const int r_hi = min(min(sg == s_lo ? s_lo_end : g.stat_seg_off[sg + 1], g.M) - m0, BM);
             double sm_ = 0.0, sq = 0.0;
-            for (int r = r_lo + part; r < r_hi; r += PARTS) { const double v = (double)T[r * BN + c]; sm_ += v; sq += v * v; }
+            if (n0 + c < g.N)
+                for (int r = r_lo + part; r < r_hi; r += PARTS) { const double v = (double)T[r * BN + c]; sm_ += v; sq += v * v; }
             red[part * BN + c] = make_double2(sm_, sq);
             __syncthreads();
-            if (t < BN) {
+            if (t < BN && n0 + t < g.N) {
                 double2 a = red[t];
 #pragma unroll
                 for (int w = 1; w < PARTS; w++) { const double2 b = red[w * BN + t]; a.x += b.x; a.y += b.y; }
@@ -816,6 +818,7 @@ struct X3Plan { int tile, splits, k_chunk; bool strip; };      // tile: 0 = 128 
 X3Plan x3_plan(int M, int N, int K)
 {
     X3Plan p{2, 1, K, false};
+    if (N == 32) { p.tile = 1; p.strip = true; return p; }     // thin: one 64-column strip tile per 128 rows (regtr_gemm_x3_supported)
     static const int strip_on = (getenv("REGTR_X3_STRIP") && *getenv("REGTR_X3_STRIP")) ? atoi(getenv("REGTR_X3_STRIP")) : 1;   // development: A/B runs
     static const int forced = (getenv("REGTR_X3_TILE") && *getenv("REGTR_X3_TILE")) ? atoi(getenv("REGTR_X3_TILE")) : -1;   // development: tile A/B runs
     static const int forced_s = (getenv("REGTR_X3_SPLITS") && *getenv("REGTR_X3_SPLITS")) ? atoi(getenv("REGTR_X3_SPLITS")) : 0;   // development
@@ -858,7 +861,13 @@ X3Plan x3_plan(int M, int N, int K)
 extern "C" {
 
 // 1 when regtr_gemm_x3 accepts the shape (otherwise use regtr_gemm_f32)
-int regtr_gemm_x3_supported(int M, int N, int K) { return (N >= 64 && N % 64 == 0 && K >= 16 && K % 4 == 0 && M >= 0) ? 1 : 0; }
+// (N = 32 -- the level-0 KPConv contractions -- only on the row-strip kernel: K a multiple of 32, no InstanceNorm folded into A)
+int regtr_gemm_x3_supported(int M, int N, int K)
+{
+    if (M < 0) return 0;
+    if (N == 32) return (K >= 64 && K % XBK == 0) ? 1 : 0;
+    return (N >= 64 && N % 64 == 0 && K >= 16 && K % 4 == 0) ? 1 : 0;
+}
 
 // Per row tile of `rows` rows (regtr_gemm_x3_stat_tile_rows / the launch's tile height): first and last cloud owning rows of the
 // tile and the first cloud's row range, 16 bytes per tile.  Built once per pyramid level and handed to every regtr_gemm_x3 launch
@@ -882,7 +891,12 @@ int regtr_gemm_x3_tile_rows(int M, int N, int K)
 
 // 1 when the split kernel is also the FASTER choice (measured on MI355X, tools/microbench.py): every supported shape with
 // at least one full k-tile; thinner contractions are pure streaming and stay on the exact-f32 kernel
-int regtr_gemm_x3_preferred(int M, int N, int K) { return (regtr_gemm_x3_supported(M, N, K) && K >= 32) ? 1 : 0; }
+int regtr_gemm_x3_preferred(int M, int N, int K)
+{
+    if (!regtr_gemm_x3_supported(M, N, K)) return 0;
+    if (N == 32) return 0;      // measured: the level-0 contraction ([2.4 M x 480] x [480 x 32], a pure A stream) 1.20 ms here vs 1.14 ms on the exact-f32 tiled kernel
+    return K >= 32 ? 1 : 0;
+}
 
 size_t regtr_gemm_split_weights_bytes(int N, int K)
 {
@@ -932,6 +946,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
     if (tile_info && a_stats && stat_partial && (a_seg_off != stat_seg_off || n_seg != n_stat_seg)) return RG_ERR_ARG;
     if (n_planes < 1 || n_planes > 3 || (n_planes != 3 && (a_stats || stat_partial))) return RG_ERR_ARG;
+    if (N == 32 && a_stats) return RG_ERR_ARG;               // the thin case exists on the row-strip kernel only
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
@@ -944,7 +959,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
              M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, n_stat_seg, a_slope};
     hipStream_t st = (hipStream_t)stream;
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
-    dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * (N / bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
+    dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * rg_cdiv(N, bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
 #define X3_LAUNCH(MW_, NW_, WM_, WN_) do { \
         if (n_planes == 1) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
         else if (n_planes == 2) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 2><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \

@@ -83,34 +83,34 @@ __global__ void __launch_bounds__(256) k_instnorm_finalize(const double2* __rest
 }
 
 // Same, from the per-(row tile, cloud) partial sums a GEMM epilogue wrote (gemm_x3.hip): the rows of cloud b live in
-// tiles off[b] / R .. (off[b+1] - 1) / R, tile t's share of cloud b is slot t + b.
+// tiles off[b] / R .. (off[b+1] - 1) / R, tile t's share of cloud b is slot t + b.  One THREAD per (cloud, channel), channels
+// across the lanes (coalesced 16-byte loads), the cloud's few slots (3 ... 75) added in slot order: a wave per (cloud, channel)
+// with a shuffle tree spent its time on launch geometry -- 131 072 one-load waves for the 1024-channel level (37 us; now 6).
 __global__ void __launch_bounds__(256) k_instnorm_finalize_tiles(const double2* __restrict__ partial, const int* __restrict__ seg_off,
                                                                  int C, int tile_rows, float eps, float2* __restrict__ stats)
 {
-    const int b = blockIdx.y, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const int lane = rg_lane();
     const int r0 = seg_off[b], r1 = seg_off[b + 1], n = r1 - r0;
-    double s = 0, ss = 0;
+    float mean = 0.f, rstd = 0.f;
     if (n > 0) {
         const int t0 = r0 / tile_rows, t1 = (r1 - 1) / tile_rows;
-        for (int t = t0 + lane; t <= t1; t += RG_WAVE) {
-            const double2 p = partial[(size_t)(t + b) * C + c];
-            s += p.x; ss += p.y;
+        const double2* p = partial + (size_t)(t0 + b) * C + c;
+        double s = 0, ss = 0;
+        int t = t0;
+        for (; t + 3 <= t1; t += 4) {                      // four independent loads in flight, added in slot order
+            const double2 a0 = p[0], a1 = p[(size_t)C], a2 = p[2 * (size_t)C], a3 = p[3 * (size_t)C];
+            s = (((s + a0.x) + a1.x) + a2.x) + a3.x; ss = (((ss + a0.y) + a1.y) + a2.y) + a3.y;
+            p += 4 * (size_t)C;
         }
+        for (; t <= t1; t++) { const double2 a = *p; s += a.x; ss += a.y; p += C; }
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
     }
-    s = rg_wave_sum(s); ss = rg_wave_sum(ss);
-    if (lane == 0) {
-        float mean = 0.f, rstd = 0.f;
-        if (n > 0) {
-            const double m = s / n;
-            double var = ss / n - m * m;
-            if (var < 0) var = 0;
-            mean = (float)m;
-            rstd = (float)(1.0 / sqrt(var + (double)eps));
-        }
-        stats[(size_t)b * C + c] = make_float2(mean, rstd);
-    }
+    stats[(size_t)b * C + c] = make_float2(mean, rstd);
 }
 
 // y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
@@ -256,7 +256,8 @@ int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int
                                   float* stats, void* stream)
 {
     if (!partial || !seg_off || !stats || n_clouds < 1 || C < 1 || tile_rows < 1) return RG_ERR_ARG;
-    k_instnorm_finalize_tiles<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, (hipStream_t)stream>>>(
+    const int bs = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+    k_instnorm_finalize_tiles<<<dim3(rg_cdiv(C, bs), n_clouds), bs, 0, (hipStream_t)stream>>>(
         (const double2*)partial, seg_off, C, tile_rows, eps, (float2*)stats);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

@@ -118,9 +118,7 @@ class SplitWeight:
             self.K, self.N = w.shape
             self.kn = w
         self.planes = None
-        # (480 x 32: the level-0 KPConv weights, for regtr_kpconv_fused)
-        if (L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K)
-                or (self.N == 32 and self.K == 480)):
+        if L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
             check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
                                              stream()), 'regtr_gemm_split_weights')
@@ -152,7 +150,8 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     ldc = out.stride(0) if M > 1 else N
     n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
     if (sw is not None and sw.planes is not None and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm
-            and L.regtr_gemm_x3_supported(M, N, K) and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
+            and L.regtr_gemm_x3_supported(M, N, K) and (N >= 64 or a_stats is None)
+            and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
         nb = L.regtr_gemm_x3_ws_bytes(M, N, K)
         ws = _ws(nb, a.device) if nb else None
         R = L.regtr_gemm_x3_stat_tile_rows(M, N, K) if (want_stats is not None and M > 0) else 0

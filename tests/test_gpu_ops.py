@@ -76,7 +76,8 @@ def test_gemm_x3_identity_asymmetric(x3_forced):
 
 @pytest.mark.parametrize('M,N,K,layout', [(751, 256, 256, 'nk'), (2753, 512, 128, 'nk'), (130, 1024, 3840, 'nk'),
                                           (9381, 256, 3840, 'kn'), (40000, 64, 960, 'kn'), (1000, 128, 32, 'nk'),
-                                          (513, 64, 16, 'nk'), (300, 768, 256, 'nk'), (70000, 128, 64, 'nk'), (1, 256, 1024, 'nk')])
+                                          (513, 64, 16, 'nk'), (300, 768, 256, 'nk'), (70000, 128, 64, 'nk'), (1, 256, 1024, 'nk'),
+                                          (70001, 32, 480, 'kn'), (300, 32, 64, 'nk')])
 def test_gemm_x3_vs_fp64(M, N, K, layout, x3_forced):
     """The bf16x3 split kernel is float32-grade: its error against float64 is within the bound used for the exact-f32
     MFMA kernel and within 2x of that kernel's own error."""
@@ -120,7 +121,7 @@ def test_gemm_x3_strided_and_fused_norm(x3_forced):
 
 
 @pytest.mark.parametrize('lens,N,K', [([700, 1300], 128, 64), ([33, 1, 64, 7, 700, 0, 300, 2, 2, 2, 61], 64, 32),
-                                      ([5000, 30000, 1], 256, 960), ([64, 64, 128], 64, 128)])
+                                      ([5000, 30000, 1], 256, 960), ([64, 64, 128], 64, 128), ([40000, 1, 30001, 77], 32, 480)])
 def test_gemm_x3_epilogue_instnorm_stats(lens, N, K, x3_forced):
     """InstanceNorm statistics emitted by the GEMM epilogue (per row-tile / cloud partial sums, tiles straddling tiny
     clouds included) == the stand-alone statistics pass over the result."""
