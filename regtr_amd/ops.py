@@ -124,6 +124,22 @@ class SplitWeight:
                                              stream()), 'regtr_gemm_split_weights')
 
 
+_x3_shape = {}       # (M, N, K) -> (supported, preferred, workspace bytes, statistics tile rows, launch tile rows): host-side plan queries, memoised
+
+
+def _x3_plan(M, N, K):
+    p = _x3_shape.get((M, N, K))
+    if p is None:
+        L = _lib.lib()
+        ok = bool(L.regtr_gemm_x3_supported(M, N, K))
+        p = (ok, bool(ok and L.regtr_gemm_x3_preferred(M, N, K)), L.regtr_gemm_x3_ws_bytes(M, N, K) if ok else 0,
+             (L.regtr_gemm_x3_stat_tile_rows(M, N, K) if M > 0 else 0) if ok else 0, L.regtr_gemm_x3_tile_rows(M, N, K) if ok else 0)
+        if len(_x3_shape) > 4096:
+            _x3_shape.clear()
+        _x3_shape[(M, N, K)] = p
+    return p
+
+
 def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_stats=None, a_seg_off=None, a_slope=0.1,
          want_stats=None, eps=1e-5, planes=3):
     """a (M,K) @ b with the fused epilogue of regtr_gemm_f32 / regtr_gemm_x3.  b: a (K,N) float32 tensor (exact-f32 MFMA
@@ -149,12 +165,11 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     lda = a.stride(0) if M > 1 else K
     ldc = out.stride(0) if M > 1 else N
     n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
-    if (sw is not None and sw.planes is not None and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm
-            and L.regtr_gemm_x3_supported(M, N, K) and (N >= 64 or a_stats is None)
-            and (force_x3_gemm or L.regtr_gemm_x3_preferred(M, N, K))):
-        nb = L.regtr_gemm_x3_ws_bytes(M, N, K)
+    x3_ok, x3_pref, nb, x3_R, x3_rows = _x3_plan(M, N, K) if sw is not None and sw.planes is not None else (False, False, 0, 0, 0)
+    if (x3_ok and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm and (N >= 64 or a_stats is None)
+            and (force_x3_gemm or x3_pref)):
         ws = _ws(nb, a.device) if nb else None
-        R = L.regtr_gemm_x3_stat_tile_rows(M, N, K) if (want_stats is not None and M > 0) else 0
+        R = x3_R if want_stats is not None else 0
         partial, s_off, n_clouds = None, None, 0
         if R:
             s_off = want_stats[0]
@@ -163,7 +178,7 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         seg_rows = s_off if R else a_seg_off                    # the cloud table of the rows, when the launch needs one
         ti = None
         if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
-            ti = tile_segments(seg_rows, M, L.regtr_gemm_x3_tile_rows(M, N, K))
+            ti = tile_segments(seg_rows, M, x3_rows)
         check(L.regtr_gemm_x3(raw(a), lda, bptr(sw.planes), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
