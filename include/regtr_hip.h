@@ -53,7 +53,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 3
+#define REGTR_ABI_VERSION 4
 int regtr_abi_version(void);
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
@@ -244,6 +244,16 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
                      const float* W1, const float* W2, const int* seg_off, int n_clouds, int max_len, const void* tile_info,
                      int M, int N, int K1, int K2, float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes,
                      float* out_stats, void* stream);
+
+/* The same tail when the second summand already exists as an [M, N] array R (identity shortcut: r_stats NULL) or is a shortcut product
+ * with its own statistics r_stats [n_clouds, N, 2]:  Y = LeakyReLU_slope( InstanceNorm(A1' W1) + [InstanceNorm](R) ), A1' =
+ * LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats [n_clouds, K1, 2] (kpconv_blocks.py:727-741).  A1' W1 is never written.
+ * Shape served: K1 = 64, N % 64 == 0.  tile_info = regtr_tile_segments(seg_off, n_clouds, M, 256, ..). */
+int regtr_block_tail_res_supported(int M, int N, int K1);
+size_t regtr_block_tail_res_ws_bytes(int n_clouds, int max_len, int N, int K1);
+int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* W1, const float* R, int ldr,
+                         const float* r_stats, const int* seg_off, int n_clouds, int max_len, const void* tile_info, int M, int N, int K1,
+                         float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes, void* stream);
 
 /* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
  * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud

@@ -20,7 +20,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 3          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 4          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -62,6 +62,9 @@ SIGNATURES = {
     'regtr_block_tail_supported': (_I, [_I, _I, _I, _I]),
     'regtr_block_tail_ws_bytes': (_Z, [_I, _I, _I, _I, _I]),
     'regtr_block_tail': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P, _P]),
+    'regtr_block_tail_res_supported': (_I, [_I, _I, _I]),
+    'regtr_block_tail_res_ws_bytes': (_Z, [_I, _I, _I, _I]),
+    'regtr_block_tail_res': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P]),
     'regtr_gemm_stream': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P, _P]),
     'regtr_gemm_x3_stat_tile_rows': (_I, [_I, _I, _I]),
     'regtr_instnorm_finalize_tiles': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),

@@ -254,6 +254,7 @@ struct TailArgs {
     const int* seg_off; const int4* tile_info;
     int M, N, lda1, lda2, ldy, n_seg;
     float a1_slope, slope;
+    const float* R; const float2* r_stats; int ldr;   // RES: + R[row, col] (identity shortcut) or + InstanceNorm(R) by r_stats [n_seg, N] (Linear shortcut)
 };
 
 // chunk swizzle of a K-bf16 LDS row (see gemm_stream.hip): CPR = K / 8 sixteen-byte chunks
@@ -278,7 +279,9 @@ __device__ __forceinline__ void ts_copy_planes(const uint16_t* __restrict__ src 
 // NT 32-column accumulators at a time, NPASS passes over the workgroup's NB = 32 NT NPASS columns: the rows stay in registers (raw),
 // fragments are remade per pass -- with all 128 columns' accumulators live the kernel needs 228 registers = one workgroup per CU
 // KT2 == 0: one source only (SimpleBlock: KPConv -> InstanceNorm -> LeakyReLU); FOLD1: source 1 is LeakyReLU(InstanceNorm(A1))
-template <int KT1, int KT2, int NT, int NPASS, bool FOLD1>
+// RES: the second operand of the block's sum is not a product computed here but a finished [M, N] array -- the block input itself
+// (identity shortcut, kpconv_blocks.py:736-739) or a shortcut product with its own statistics -- added in the epilogue.
+template <int KT1, int KT2, int NT, int NPASS, bool FOLD1, bool RES = false>
 __global__ void __launch_bounds__(TS_WAVES* RG_WAVE, NT <= 2 ? 4 : 2) k_tail_strip(TailArgs g)
 {
     constexpr int K1 = 16 * KT1, K2 = 16 * KT2, NB = 32 * NT * NPASS, KT2A = KT2 > 0 ? KT2 : 1;
@@ -391,6 +394,18 @@ __global__ void __launch_bounds__(TS_WAVES* RG_WAVE, NT <= 2 ? 4 : 2) k_tail_str
             for (int j = 0; j < NT; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+            // RES: the pass's residual values are requested BEFORE its MFMAs, branch free (clamped rows; a predicated load in the store
+            // loop would be waited for one at a time): they arrive under the matrix work
+            float rv[RES ? NT : 1][RES ? 16 : 1];
+            if constexpr (RES) {
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int rw = min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1);
+                        rv[j][r] = g.R[(size_t)rw * g.ldr + n0 + cb + 32 * j + l31];
+                    }
+            }
 #define TS_STEP(FA, WS_, OFF, KK)                                                                                            \
             _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                                   \
                 bf16x8 fb[3];                                                                                                  \
@@ -414,18 +429,32 @@ __global__ void __launch_bounds__(TS_WAVES* RG_WAVE, NT <= 2 ? 4 : 2) k_tail_str
             int rb = rbase;
             asm volatile("" : "+v"(rb));
 #pragma unroll
-            for (int j = 0; j < NT; j++)
+            for (int j = 0; j < NT; j++) {
+                const int col = n0 + cb + 32 * j + l31;
+                float2 rst = make_float2(0.f, 1.f);
+                if constexpr (RES) { if (g.r_stats) rst = g.r_stats[(size_t)sg * N + col]; }
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int rw = rb + (r & 3) + 8 * (r >> 2);
-                    const float v = acc[j][r];
-                    if (rw >= c_lo && rw < c_hi) g.Y[(size_t)rw * g.ldy + n0 + cb + 32 * j + l31] = fmaxf(v, v * g.slope);
+                    float v = acc[j][r];
+                    if (rw >= c_lo && rw < c_hi) {
+                        if constexpr (RES) v += (rv[j][r] - rst.x) * rst.y;
+                        g.Y[(size_t)rw * g.ldy + col] = fmaxf(v, v * g.slope);
+                    }
                 }
+            }
         }
     }
 }
 
 int bt_chunks(int max_len) { return rg_cdiv(max_len > 0 ? max_len : 1, MO_ROWS_WG); }
+size_t bt_align(size_t b);
+size_t bt_res_ws_bytes(int n_clouds, int max_len, int N, int K1)
+{
+    const size_t nc = (size_t)bt_chunks(max_len);
+    return ((n_clouds * nc * (K1 * K1 + K1) * 8 + 255) & ~(size_t)255) + (((size_t)n_clouds * 3 * N * K1 * 2 + 255) & ~(size_t)255) +
+           (((size_t)n_clouds * K1 * 4 + 255) & ~(size_t)255);
+}
 size_t bt_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -478,7 +507,7 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
     hipStream_t st = (hipStream_t)stream;
     const dim3 mgrid(nc, n_clouds), pgrid(n_clouds, N / 64), sgrid(rg_cdiv(M, TS_ROWS), 1);
     TailArgs g{A1, A2, Y, (const float2*)a1_stats, row_div1, mean1, mean2, planes1, planes2, seg_off, (const int4*)tile_info,
-               M, N, lda1, lda2, ldy, n_clouds, a1_slope, slope};
+               M, N, lda1, lda2, ldy, n_clouds, a1_slope, slope, nullptr, nullptr, 0};
     const size_t lds = (size_t)3 * N * (K1 + K2) * 2;                // the workgroup holds all N columns
     if (K2 > 0) {
         k_moments<1, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1);
@@ -493,6 +522,54 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
                                                      (float2*)out_stats, n_clouds);
         if (!rg_allow_dynamic_lds<k_tail_strip<1, 0, 2, 1, false>>(lds)) return RG_ERR_ARG;
         k_tail_strip<1, 0, 2, 1, false><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
+    }
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
+// The tail of a resnet block whose second summand already exists (csrc/block_tail.hip, RES):
+//     Y = LeakyReLU_slope( InstanceNorm(A1' W1) + R )                      r_stats == NULL: identity shortcut (kpconv_blocks.py:736-741)
+//     Y = LeakyReLU_slope( InstanceNorm(A1' W1) + InstanceNorm_r_stats(R) ) r_stats [n_clouds, N, 2]: a Linear shortcut's product
+// with A1' = LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats.  The product A1' W1 is never written: its statistics come from the K1 x K1
+// second moments of A1', the normalisation is folded into per-cloud weight planes, R is added in the strip GEMM's epilogue -- one pass
+// (read A1, R; write Y) instead of GEMM + statistics + normalise-add pass.  Shape served: K1 = 64, N a multiple of 64 (level 1 of the
+// 3DMatch encoder: 64 -> 256).  ws: regtr_block_tail_res_ws_bytes.
+int regtr_block_tail_res_supported(int M, int N, int K1) { return (M >= 0 && K1 == 64 && N >= 64 && N % 64 == 0) ? 1 : 0; }
+
+size_t regtr_block_tail_res_ws_bytes(int n_clouds, int max_len, int N, int K1)
+{
+    if (n_clouds < 1 || !regtr_block_tail_res_supported(0, N, K1)) return 0;
+    return bt_res_ws_bytes(n_clouds, max_len, N, K1);
+}
+
+int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* W1, const float* R, int ldr,
+                         const float* r_stats, const int* seg_off, int n_clouds, int max_len, const void* tile_info, int M, int N, int K1,
+                         float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes, void* stream)
+{
+    if (!A1 || !a1_stats || !W1 || !R || !seg_off || !tile_info || !Y || !ws || n_clouds < 1 || max_len < 0) return RG_ERR_ARG;
+    if (!regtr_block_tail_res_supported(M, N, K1) || lda1 < K1 || ldy < N || ldr < N || (lda1 % 4)) return RG_ERR_ARG;
+    if (((uintptr_t)A1 | (uintptr_t)a1_stats | (uintptr_t)tile_info | (uintptr_t)ws) % 16) return RG_ERR_ARG;
+    if (ws_bytes < bt_res_ws_bytes(n_clouds, max_len, N, K1)) return RG_ERR_WORKSPACE;
+    if (M == 0 || max_len == 0) return RG_OK;
+    const int nc = bt_chunks(max_len);
+    unsigned char* p = (unsigned char*)ws;
+    double* part1 = (double*)p; p += bt_align((size_t)n_clouds * nc * (K1 * K1 + K1) * 8);
+    uint16_t* planes1 = (uint16_t*)p; p += bt_align((size_t)n_clouds * 3 * N * K1 * 2);
+    float* mean1 = (float*)p;
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = N % 256 == 0;                                  // a workgroup holds 256 (else 64) columns of the cloud's planes: A is read once
+    const int nbw = wide ? 256 : 64;
+    const dim3 mgrid(nc, n_clouds), pgrid(n_clouds, N / 64), sgrid(rg_cdiv(M, TS_ROWS), N / nbw);
+    TailArgs g{A1, nullptr, Y, (const float2*)a1_stats, nullptr, mean1, nullptr, planes1, nullptr, seg_off, (const int4*)tile_info,
+               M, N, lda1, 0, ldy, n_clouds, a1_slope, slope, R, (const float2*)r_stats, ldr};
+    const size_t lds = (size_t)3 * nbw * K1 * 2;
+    k_moments<2, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1);
+    k_tail_prepare<64, 0><<<pgrid, 256, 0, st>>>(part1, nullptr, seg_off, nc, W1, nullptr, N, eps, planes1, nullptr, mean1, nullptr, nullptr, n_clouds);
+    if (wide) {
+        if (!rg_allow_dynamic_lds<k_tail_strip<4, 0, 4, 2, true, true>>(lds)) return RG_ERR_ARG;
+        k_tail_strip<4, 0, 4, 2, true, true><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
+    } else {
+        k_tail_strip<4, 0, 2, 1, true, true><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
     }
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

@@ -309,12 +309,17 @@ class ResnetBottleneckBlock(nn.Module):
             ws = _prepared(self.unary_shortcut._cache, 'w', self.unary_shortcut.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
             if ops.block_tail_ok(x, st, features, w2, ws):
                 return ops.block_tail(x, st, features, w2, ws, v.seg_post, v.max_post)
-        # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
-        y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
         shortcut = ops.maxpool(features, v.inds, v.pool_width) if strided else features                                     # :734-737
         sc_st = None
         if isinstance(self.unary_shortcut, UnaryBlock):
             shortcut, sc_st = self.unary_shortcut.linear(shortcut, v.seg_post, v.max_post)
+        # unary2's statistics from the second moments of its narrow input; the finished second summand is added in the strip GEMM's
+        # epilogue: the unary2 product is never written and the normalise-add pass disappears (csrc/block_tail.hip, RES)
+        w2 = _prepared(self.unary2._cache, 'w', self.unary2.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
+        if ops.block_tail_res_ok(x, st, w2, shortcut):
+            return ops.block_tail_res(x, st, w2, shortcut, sc_st, v.seg_post, v.max_post)
+        # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
+        y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
         # LeakyReLU( IN(unary2) + [IN](shortcut) ) in one pass                                                :741
         return ops.instnorm_apply(y, v.seg_post, v.max_post, y_st, residual=shortcut, res_stats=sc_st, lrelu=True, out=y)
 

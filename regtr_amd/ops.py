@@ -278,6 +278,31 @@ def _block_tail(x1, x1_stats, row_div, f, w1_kn, w2_kn, seg_off, max_len, slope,
     return (y, st) if want_stats else y
 
 
+def block_tail_res_ok(x1, x1_stats, sw1, res):
+    """regtr_block_tail_res serves this block tail (unary2 from input moments, the finished second summand added in the epilogue)."""
+    M, K1 = x1.shape
+    return bool(use_block_tail and use_block_tail_res and not force_f32_gemm and not force_x3_gemm and M >= STREAM_MIN_ROWS and x1_stats is not None
+                and res.shape == (M, sw1.N) and x1.stride(1) == 1 and res.stride(1) == 1 and x1.stride(0) % 4 == 0
+                and x1.data_ptr() % 16 == 0 and x1_stats.data_ptr() % 16 == 0 and _lib.lib().regtr_block_tail_res_supported(M, sw1.N, K1))
+
+
+def block_tail_res(x1, x1_stats, sw1, res, res_stats, seg_off, max_len, slope=0.1, eps=1e-5):
+    """LeakyReLU(InstanceNorm(x1' @ W1) + r), x1' = LeakyReLU(InstanceNorm(x1)) by x1_stats, r = res (identity / max-pooled shortcut,
+    kpconv_blocks.py:734-741) or InstanceNorm(res) by res_stats (n_clouds, N, 2) (a Linear shortcut's product): unary2 is never written."""
+    L = _lib.lib()
+    M, K1 = x1.shape
+    N = sw1.N
+    n_clouds = seg_off.numel() - 1
+    nb = L.regtr_block_tail_res_ws_bytes(n_clouds, int(max_len), N, K1)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x1.device)
+    ti = tile_segments(seg_off, M, 256)
+    y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
+    check(L.regtr_block_tail_res(raw(x1), x1.stride(0), ptr(x1_stats), slope, ptr(sw1.kn), raw(res), res.stride(0), ptr(res_stats),
+                                 iptr(seg_off), n_clouds, int(max_len), iptr(ti), M, N, K1, eps, slope, ptr(y), N, bptr(ws), nb, stream()),
+          'regtr_block_tail_res')
+    return y
+
+
 def first_block_ok(nq, Cin, KP, Cout):
     """kpconv_norm_lrelu serves the encoder's first block (one input feature, 15 kernel points, 64 outputs, a tall batch)."""
     return bool(use_block_tail and not force_f32_gemm and not force_x3_gemm and Cin == 1 and KP == 15 and nq >= STREAM_MIN_ROWS
@@ -306,6 +331,7 @@ use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B ru
 # kernels at level 0 of a 64-pair forward (two workgroup barriers per query round) -- off until it is pipelined
 use_fused_kpconv = os.environ.get('REGTR_FUSED_KPCONV', '0') != '0'
 use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
+use_block_tail_res = os.environ.get('REGTR_BLOCK_TAIL_RES', '1') != '0'       # A-B runs: ... with the finished second summand added in the epilogue (level 1)
 PRENORM_MIN_ROWS = 65536        # below this a forward is launch-bound: the extra normalise pass costs more than the gather saves
 prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
 use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs

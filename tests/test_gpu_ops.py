@@ -554,6 +554,40 @@ def test_gemm_stream_vs_exact_f32(lens, K, N):
 
 
 @pytest.mark.parametrize('lens', [[70000], [20000, 0, 33001, 12999], [300, 66000, 5], [1000] * 70])
+@pytest.mark.parametrize('linear_shortcut', [False, True])
+def test_block_tail_res_vs_separate_ops(lens, linear_shortcut):
+    """regtr_block_tail_res (level-1 resnet tails: unary2's statistics from the 64 x 64 second moments of its input, the product never
+    written, the finished second summand -- identity / max-pooled shortcut, or a Linear shortcut's product with its statistics --
+    added in the epilogue) against unary2 GEMM + instnorm_apply with the residual."""
+    ops = _ops()
+    rng = np.random.default_rng(len(lens) + 7)
+    M, K1, N = sum(lens), 64, 256
+    seg = seg_of(lens)
+    x1 = (rng.standard_normal((M, K1)) * rng.uniform(0.3, 3, K1) + rng.uniform(-2, 2, K1)).astype(np.float32)
+    x1[:, 9] = 0.5 * x1[:, 8] - 1.0                      # correlated channels: the covariance terms matter
+    res = (rng.standard_normal((M, N)) * rng.uniform(0.3, 2, N) + rng.uniform(-1, 1, N)).astype(np.float32)
+    w1 = (rng.standard_normal((N, K1)) / math.sqrt(K1)).astype(np.float32)
+    w1[11] *= 1e-3                                       # a nearly dead output column (eps dominates its rstd)
+    x1d, rd = to_dev(x1), to_dev(res)
+    sw1 = ops.SplitWeight(to_dev(w1), 'nk')
+    x1_st = ops.instnorm_stats(x1d, seg, max(lens))
+    r_st = ops.instnorm_stats(rd, seg, max(lens)) if linear_shortcut else None
+    assert ops.block_tail_res_ok(x1d, x1_st, sw1, rd) == (M >= ops.STREAM_MIN_ROWS)
+    y = ops.block_tail_res(x1d, x1_st, sw1, rd, r_st, seg, max(lens))
+    u, u_st = ops.gemm(x1d, sw1, a_stats=x1_st, a_seg_off=seg, want_stats=(seg, max(lens)))
+    ref = ops.instnorm_apply(u, seg, max(lens), u_st, residual=rd, res_stats=r_st, lrelu=True)
+    assert (y - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    # float64 reference of the whole expression on one cloud
+    from oracle import regtr_ref
+    L = torch.tensor(lens)
+    xn = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(x1).double(), L), 0.1)
+    un = regtr_ref.instance_norm(xn @ torch.from_numpy(w1).double().t(), L)
+    rn = regtr_ref.instance_norm(torch.from_numpy(res).double(), L) if linear_shortcut else torch.from_numpy(res).double()
+    want = torch.nn.functional.leaky_relu(un + rn, 0.1)
+    assert (y.cpu().double() - want).abs().max().item() < 5e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize('lens', [[70000], [20000, 0, 33001, 12999], [300, 66000, 5], [1000] * 70])
 def test_block_tail_vs_separate_ops(lens):
     """regtr_block_tail (statistics from input moments, neither product written) against unary2 GEMM + shortcut GEMM +
     instnorm_apply, and its reported product statistics against float64."""
