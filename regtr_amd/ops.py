@@ -331,7 +331,10 @@ use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B ru
 # kernels at level 0 of a 64-pair forward (two workgroup barriers per query round) -- off until it is pipelined
 use_fused_kpconv = os.environ.get('REGTR_FUSED_KPCONV', '0') != '0'
 use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
-use_block_tail_res = os.environ.get('REGTR_BLOCK_TAIL_RES', '1') != '0'       # A-B runs: ... with the finished second summand added in the epilogue (level 1)
+# ... with the finished second summand added in the epilogue (level 1: unary2 64 -> 256 never written).  Correct and tested, but NOT faster:
+# moments 130 + prepare 68 + strip 410 us against strip GEMM 230 + normalise-add pass 340 us per level-1 block; 30.42 vs 30.17 ms per
+# 64-pair forward -- off by default
+use_block_tail_res = os.environ.get('REGTR_BLOCK_TAIL_RES', '0') != '0'
 PRENORM_MIN_ROWS = 65536        # below this a forward is launch-bound: the extra normalise pass costs more than the gather saves
 prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
 use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs

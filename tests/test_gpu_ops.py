@@ -572,7 +572,12 @@ def test_block_tail_res_vs_separate_ops(lens, linear_shortcut):
     sw1 = ops.SplitWeight(to_dev(w1), 'nk')
     x1_st = ops.instnorm_stats(x1d, seg, max(lens))
     r_st = ops.instnorm_stats(rd, seg, max(lens)) if linear_shortcut else None
-    assert ops.block_tail_res_ok(x1d, x1_st, sw1, rd) == (M >= ops.STREAM_MIN_ROWS)
+    prev = ops.use_block_tail_res
+    ops.use_block_tail_res = True
+    try:
+        assert ops.block_tail_res_ok(x1d, x1_st, sw1, rd) == (M >= ops.STREAM_MIN_ROWS)      # (off by default: a speed choice)
+    finally:
+        ops.use_block_tail_res = prev
     y = ops.block_tail_res(x1d, x1_st, sw1, rd, r_st, seg, max(lens))
     u, u_st = ops.gemm(x1d, sw1, a_stats=x1_st, a_seg_off=seg, want_stats=(seg, max(lens)))
     ref = ops.instnorm_apply(u, seg, max(lens), u_st, residual=rd, res_stats=r_st, lrelu=True)
