@@ -51,9 +51,11 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
     {
         const int qrow = q0 + l31;
         const bool live = qrow < q_end;
+        // branch free (clamped row, scale 0 for a dead lane): `live ? load : 0` is sixteen predicated loads with a full wait each
+        const float* qp = g.q + (size_t)(live ? qrow : q_begin) * g.ldq + hoff + hi;
+        const float scl = live ? g.scale : 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-            qreg[s] = live ? g.q[(size_t)qrow * g.ldq + hoff + 2 * s + hi] * g.scale : 0.f;
+        for (int s = 0; s < 16; s++) qreg[s] = qp[2 * s] * scl;
     }
 
     floatx16 o;
@@ -67,13 +69,11 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int it = 0; it < 4; it++) {
-            const int krow = kt + it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-            kreg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            vreg[it] = kreg[it];
-            if (krow < nk) {
-                kreg[it] = *(const float4*)(g.k + (size_t)(k_begin + krow) * g.ldk + hoff + c4);
-                vreg[it] = *(const float4*)(g.v + (size_t)(k_begin + krow) * g.ldv + hoff + c4);
-            }
+            // clamped rows, no predicate (see k_mha_fwd_bf16): keys past nk are masked to -inf below, their values meet p = 0
+            const int krow = min(kt + it * 8 + (lane >> 3), nk > 0 ? nk - 1 : 0), c4 = (lane & 7) * 4;
+            const int kb = nk > 0 ? k_begin : q_begin;
+            kreg[it] = *(const float4*)(g.k + (size_t)(kb + krow) * g.ldk + hoff + c4);
+            vreg[it] = *(const float4*)(g.v + (size_t)(kb + krow) * g.ldv + hoff + c4);
         }
     };
     fetch(0);
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
             vd[0] = vreg[it].x; vd[1] = vreg[it].y; vd[2] = vreg[it].z; vd[3] = vreg[it].w;
         }
         __syncthreads();
-        if (kt + TK < nk) fetch(kt + TK);
+        fetch(kt + TK);                  // unconditional: rows are clamped
 
         // S^T tile: rows = keys, cols = queries
         floatx16 sc;
@@ -224,11 +224,16 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
         const bool live = wave_live && qrow < q_end;
         const float sc2 = g.scale * 1.44269504088896340736f;
         const float* qp = g.q + (size_t)(live ? qrow : q_begin) * g.ldq + hoff + 8 * hi;
+        // (all four 16-byte loads first, from the clamped row, THEN the select: `live ? load : 0` per element compiles to sixteen
+        //  predicated dword loads with a full wait each)
+        float4 qv[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) { qv[ks][0] = *(const float4*)(qp + 16 * ks); qv[ks][1] = *(const float4*)(qp + 16 * ks + 4); }
+        const float scl = live ? sc2 : 0.f;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) x[j] = live ? qp[16 * ks + j] * sc2 : 0.f;
+            const float x[8] = {qv[ks][0].x * scl, qv[ks][0].y * scl, qv[ks][0].z * scl, qv[ks][0].w * scl,
+                                qv[ks][1].x * scl, qv[ks][1].y * scl, qv[ks][1].z * scl, qv[ks][1].w * scl};
             bf_split8<NP>(x, qf[ks]);
         }
     }
@@ -244,24 +249,29 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
         const unsigned row = (unsigned)(sd2 + dd);
         v_dst[dd] = row * BROW + (((vpos >> 3) ^ ((row >> 2) & 3u)) * 16u) + (vpos & 7u) * 2u;
     }
-    float4 kreg;
-    float2 vreg0, vreg1;
-    auto fetch = [&](int kt) {
-        const int kr = kt + skey, v0 = kt + 2 * su;
-        kreg = make_float4(0.f, 0.f, 0.f, 0.f);
-        vreg0 = make_float2(0.f, 0.f); vreg1 = vreg0;
-        if (kr < nk) kreg = *(const float4*)(g.k + (size_t)(k_begin + kr) * g.ldk + hoff + sd4);
-        if (v0 < nk) vreg0 = *(const float2*)(g.v + (size_t)(k_begin + v0) * g.ldv + hoff + sd2);
-        if (v0 + 1 < nk) vreg1 = *(const float2*)(g.v + (size_t)(k_begin + v0 + 1) * g.ldv + hoff + sd2);
+    // K / V rows travel global -> registers -> (split) -> LDS.  TWO register sets: the rows of tile t + 2 are requested while tile t
+    // is multiplied and tile t + 1's set -- requested a whole tile earlier -- is split and stored; with one set the store pass waited
+    // ~700 cycles per tile for loads issued one compute phase before (phase clocks, profiles/r03_mha_phase_clocks.md).
+    struct KV { float4 k; float2 v0, v1; };
+    // BRANCH-FREE loads from clamped rows: a predicated load (`x = 0; if (row < nk) x = load`) becomes load + select, and the select's
+    // wait exposes the whole L2 latency right at the issue point -- phase clocks showed 1575 of 4800 cycles per key tile there.  Keys past
+    // nk need no zeroing: their scores are masked to -inf below, so their (finite, clamped-row) values meet p = 0.
+    const int nk1 = nk > 0 ? nk - 1 : 0;
+    const int kb = nk > 0 ? k_begin : q_begin;         // an empty key cloud: read (and never use) a row of the live query cloud
+    auto fetch = [&](KV& r, int kt) {
+        const int kr = min(kt + skey, nk1), v0 = min(kt + 2 * su, nk1), v1 = min(kt + 2 * su + 1, nk1);
+        r.k = *(const float4*)(g.k + (size_t)(kb + kr) * g.ldk + hoff + sd4);
+        r.v0 = *(const float2*)(g.v + (size_t)(kb + v0) * g.ldv + hoff + sd2);
+        r.v1 = *(const float2*)(g.v + (size_t)(kb + v1) * g.ldv + hoff + sd2);
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](const KV& r, int buf) {
         unsigned a[NP], b[NP];
-        bf_split2<NP>(kreg.x, kreg.y, a);
-        bf_split2<NP>(kreg.z, kreg.w, b);
+        bf_split2<NP>(r.k.x, r.k.y, a);
+        bf_split2<NP>(r.k.z, r.k.w, b);
 #pragma unroll
         for (int p = 0; p < NP; p++) *(uint2*)(&Ks[buf][p][k_dst]) = make_uint2(a[p], b[p]);
-        bf_split2<NP>(vreg0.x, vreg1.x, a);           // (key 2u, key 2u + 1) of channel sd2
-        bf_split2<NP>(vreg0.y, vreg1.y, b);           // ... of channel sd2 + 1
+        bf_split2<NP>(r.v0.x, r.v1.x, a);             // (key 2u, key 2u + 1) of channel sd2
+        bf_split2<NP>(r.v0.y, r.v1.y, b);             // ... of channel sd2 + 1
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             *(unsigned*)(&Vt[buf][p][v_dst[0]]) = a[p];
@@ -277,13 +287,25 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) f_off[ks] = (unsigned)l31 * BROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
 
-    fetch(0);
-    stage(0);
+#ifdef MHA_PROF          // development: per-wave phase clocks (REGTR_VARIANT_FLAGS=-DMHA_PROF)
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = clock64(), pstart = pc;
+#define MHA_STAMP(I) do { const long long n_ = clock64(); pt[I] += n_ - pc; pc = n_; } while (0)
+#else
+#define MHA_STAMP(I) do {} while (0)
+#endif
+    KV ra, rb;
+    fetch(ra, 0);
+    stage(ra, 0);
+    fetch(ra, TK);                                     // tile 1 (clamped rows past the end: never used)
     __syncthreads();
-    int buf = 0;
-    for (int kt = 0; kt < nk; kt += TK, buf ^= 1) {
+    MHA_STAMP(0);
+    // one key tile: request tile kt + 2 into `rnew`, multiply tile kt from LDS slot `buf`, split + store tile kt + 1 (`rold`, requested a
+    // tile ago) into the other slot.  The fetch is unconditional (rows are clamped): under `if (more)` the loop-carried registers get phi
+    // copies placed right behind the loads, and a wait for them at the issue point.
+    auto tile = [&](int kt, int buf, KV& rold, KV& rnew) {
         const bool more = kt + TK < nk;                // workgroup-uniform
-        if (more) fetch(kt + TK);
+        fetch(rnew, kt + 2 * TK);
+        MHA_STAMP(1);
         if (wave_live) {
             floatx16 sc;
 #pragma unroll
@@ -295,6 +317,7 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
                 for (int p = 0; p < NP; p++) kf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Ks[buf][p][f_off[ks]]));
                 sc = bf_mma<NP>(kf, qf[ks], sc);
             }
+            MHA_STAMP(2);
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -327,10 +350,23 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
                 for (int p = 0; p < NP; p++) vf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Vt[buf][p][f_off[ks]]));
                 o = bf_mma<NP>(vf, pf, o);
             }
+            MHA_STAMP(3);
         }
-        if (more) stage(buf ^ 1);
+        if (more) stage(rold, buf ^ 1);
+        MHA_STAMP(4);
         __syncthreads();
+        MHA_STAMP(5);
+    };
+    for (int kt = 0; kt < nk; kt += 2 * TK) {
+        tile(kt, 0, ra, rb);
+        if (kt + TK >= nk) break;
+        tile(kt + TK, 1, rb, ra);
     }
+#ifdef MHA_PROF
+    if ((blockIdx.z == 3 || blockIdx.z == 77) && blockIdx.y == 2 && lane == 0)
+        printf("mha NP %d cloud %d wg %d wave %d live %d nk %d: prologue %lld fetch-issue %lld qk %lld softmax+pv %lld stage %lld barrier %lld total %lld (cycles)\n", NP,
+               (int)blockIdx.z, (int)blockIdx.x, wave, (int)wave_live, nk, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], clock64() - pstart);
+#endif
 
     const int qrow = q0 + l31;
     if (wave_live && qrow < q_end) {
@@ -461,7 +497,7 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
 {
     if (!q || !k || !v || !out || !seg_off || !kv_of || n_clouds < 1 || n_heads < 1 || max_len < 0) return RG_ERR_ARG;
     if (head_dim != HD || precision < 0 || precision > 2) return RG_ERR_ARG;
-    if ((ldk | ldv | ldo) % 4 || (((uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
+    if ((ldq | ldk | ldv | ldo) % 4 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
     MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
     hipStream_t st = (hipStream_t)stream;

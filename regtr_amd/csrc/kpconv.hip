@@ -715,6 +715,41 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
 
 }  // namespace
 
+// The same, BRANCH FREE.  The .s of the kernel above is a chain of `global_load ; s_waitcnt vmcnt(0)` pairs -- every index load and every
+// row load sits in its own predicated block, so the "8 rows in flight" never were: one dependent round trip after the other (index,
+// row, index, row ...).  Here the index row is read with clamped column numbers (a repeated neighbour does not change a maximum), the
+// feature rows with range-checked buffer loads (an offset of RG_OOB returns zeros: exactly the zero shadow row), HB rows per batch
+// all issued before the first maximum.  Needs ns * C * 4 < 2^31 (buffer offsets).
+template <int QW, int HB>
+__global__ void __launch_bounds__(256) k_maxpool_gather_buf(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
+                                                            int ld_nbr, int nq, int H, float* __restrict__ out)
+{
+    constexpr int LQ = RG_WAVE / QW;                 // lanes per query
+    const int lane = rg_lane();
+    const int q = (rg_xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * QW + lane / LQ;      // XCD-contiguous
+    const int qc = q < nq ? q : nq - 1;              // a dead lane repeats the last query (it never stores)
+    const int* row = nbr + (size_t)qc * ld_nbr;
+    const unsigned row_bytes = (unsigned)C * 4u;
+    const __amdgpu_buffer_rsrc_t x_rs = rg_rsrc(x, (unsigned)ns * row_bytes);
+    for (int c = (lane % LQ) * 4; c < C; c += LQ * 4) {
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        const unsigned cb = (unsigned)c * 4u;
+        for (int h0 = 0; h0 < H; h0 += HB) {
+            int idx[HB];
+#pragma unroll
+            for (int u = 0; u < HB; u++) idx[u] = row[min(h0 + u, H - 1)];
+            float4 v[HB];
+#pragma unroll
+            for (int u = 0; u < HB; u++) v[u] = rg_buf_load<4>(x_rs, (unsigned)idx[u] < (unsigned)ns ? (unsigned)idx[u] * row_bytes + cb : RG_OOB);
+#pragma unroll
+            for (int u = 0; u < HB; u++) {
+                m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
+            }
+        }
+        if (q < nq) *(float4*)(out + (size_t)q * C + c) = m;
+    }
+}
+
 extern "C" {
 
 int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
@@ -811,6 +846,13 @@ int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_n
 {
     if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || ld_nbr < H || C < 4 || C % 4) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
+    if (ns > 0 && (unsigned long long)ns * C * 4ull < 0x80000000ull && ((uintptr_t)x % 16) == 0) {      // the branch-free form (buffer offsets < 2 GiB)
+        if (C <= 64) k_maxpool_gather_buf<4, 8><<<rg_xcd_grid(rg_cdiv(nq, 16)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+        else if (C <= 128) k_maxpool_gather_buf<2, 8><<<rg_xcd_grid(rg_cdiv(nq, 8)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+        else k_maxpool_gather_buf<1, 8><<<rg_xcd_grid(rg_cdiv(nq, 4)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
+        RG_RETURN_IF_LAUNCH_FAILED();
+        return RG_OK;
+    }
     if (C <= 64) k_maxpool_gather<4><<<rg_xcd_grid(rg_cdiv(nq, 16)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
     else if (C <= 128) k_maxpool_gather<2><<<rg_xcd_grid(rg_cdiv(nq, 8)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
     else k_maxpool_gather<1><<<rg_xcd_grid(rg_cdiv(nq, 4)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
