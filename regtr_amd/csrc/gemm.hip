@@ -33,33 +33,44 @@ struct GemmArgs {
     float a_slope;
 };
 
+// Operand tiles into registers.  Every load is UNCONDITIONAL, from a clamped row / column / k, and NOTHING here consumes a loaded
+// value (clamped garbage lands in rows and columns that are never stored; what lies beyond k_end is zeroed by stage() from the
+// returned mask, when the registers go to LDS two tiles later): a load under a per-lane predicate, or one whose value feeds a
+// select right away, compiles to load + s_waitcnt vmcnt(0) -- the tile's loads became serial memory round trips in front of the
+// MFMAs they were meant to hide behind (tools/isa_scan.py).  mask: bit 4 i + j = element j of A vector i is inside k_end,
+// bit 16 + 4 i + j the same for B (also inside N).
 template <bool ALIGNED, int BM, int BN>
-__device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, int k0, int k_end,
-                                           float (&ra)[BM * BK / 1024][4], float (&rb)[BK * BN / 1024][4], const int* row_seg)
+__device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0, int k0, int k_end,
+                                               float (&ra)[BM * BK / 1024][4], float (&rb)[BK * BN / 1024][4], const int* row_seg)
 {
     const int t = threadIdx.x;
     constexpr int KV = BK / 4;                      // float4 per A row
+    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < BM * BK / 1024; i++) {      // A: BM rows x BK k -> (row = idx / KV, k4 = (idx % KV) * 4)
         const int idx = t + i * 256;
-        const int row = m0 + idx / KV, k = k0 + (idx % KV) * 4;
-        if (ALIGNED) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < g.M && k < k_end) v = *(const float4*)(g.A + (size_t)row * g.lda + k);
+        const int row = min(m0 + idx / KV, g.M - 1), k = k0 + (idx % KV) * 4;
+        if (ALIGNED) {                              // (k_end % 4 == 0: a float4 is wholly inside or wholly outside)
+            const float4 v = *(const float4*)(g.A + (size_t)row * g.lda + min(k, k_end - 4));
             ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
+            mask |= (k < k_end ? 0xfu : 0u) << (4 * i);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) ra[i][j] = (row < g.M && k + j < k_end) ? g.A[(size_t)row * g.lda + k + j] : 0.f;
+            for (int j = 0; j < 4; j++) {
+                ra[i][j] = g.A[(size_t)row * g.lda + min(k + j, k_end - 1)];
+                mask |= (k + j < k_end ? 1u : 0u) << (4 * i + j);
+            }
         }
-        if (g.a_stats && row < g.M) {
-            const float2* st = g.a_stats + (size_t)row_seg[i] * g.K + k;
+        if (g.a_stats) {                            // (the folded-InstanceNorm operand: rare on this kernel, transformed at once)
+            const float2* st = g.a_stats + (size_t)row_seg[i] * g.K;
+            float2 s[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (k + j < k_end) {
-                    const float2 s = st[j];
-                    const float v = (ra[i][j] - s.x) * s.y;
-                    ra[i][j] = v > 0.f ? v : v * g.a_slope;
-                }
+            for (int j = 0; j < 4; j++) s[j] = st[min(k + j, k_end - 1)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float v = (ra[i][j] - s[j].x) * s[j].y;
+                ra[i][j] = v > 0.f ? v : v * g.a_slope;
+            }
         }
     }
     constexpr int NV = BN / 4;                      // float4 per B row
@@ -67,17 +78,20 @@ __device__ __forceinline__ void load_tiles(const GemmArgs& g, int m0, int n0, in
     for (int i = 0; i < BK * BN / 1024; i++) {      // B: BK k x BN n -> (k = idx / NV, n4 = (idx % NV) * 4)
         const int idx = t + i * 256;
         const int k = k0 + idx / NV, n = n0 + (idx % NV) * 4;
-        rb[i][0] = rb[i][1] = rb[i][2] = rb[i][3] = 0.f;
-        if (ALIGNED) {
-            if (k < k_end && n < g.N) {
-                const float4 v = *(const float4*)(g.B + (size_t)k * g.ldb + n);
-                rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
-            }
+        const int kc = min(k, k_end - 1);
+        if (ALIGNED) {                              // (N % 4 == 0)
+            const float4 v = *(const float4*)(g.B + (size_t)kc * g.ldb + min(n, g.N - 4));
+            rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
+            mask |= ((k < k_end && n < g.N) ? 0xfu : 0u) << (16 + 4 * i);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) rb[i][j] = (k < k_end && n + j < g.N) ? g.B[(size_t)k * g.ldb + n + j] : 0.f;
+            for (int j = 0; j < 4; j++) {
+                rb[i][j] = g.B[(size_t)kc * g.ldb + min(n + j, g.N - 1)];
+                mask |= ((k < k_end && n + j < g.N) ? 1u : 0u) << (16 + 4 * i + j);
+            }
         }
     }
+    return mask;
 }
 
 // WMW x WNW waves, each a 32x32 accumulator
@@ -117,18 +131,21 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     // tile t and only written to LDS after the MFMAs of tile t+1, so every load has ~2 tiles of matrix-core work
     // (>= 2048 cycles) to cover its L2 / Infinity-Cache latency even with a single workgroup per CU.
     float ra0[AV][4], rb0[BV][4], ra1[AV][4], rb1[BV][4];
-    auto stage = [&](int buf, float (&ra)[AV][4], float (&rb)[BV][4]) {
+    unsigned in0 = 0, in1 = 0;                    // load_tiles' in-range masks of the two register stages
+    auto stage = [&](int buf, float (&ra)[AV][4], float (&rb)[BV][4], unsigned in) {
 #pragma unroll
         for (int i = 0; i < AV; i++) {
             const int idx = t + i * 256;
             float* a = &As[buf][(idx / KV) * LDA_S + (idx % KV) * 4];
-            a[0] = ra[i][0]; a[1] = ra[i][1]; a[2] = ra[i][2]; a[3] = ra[i][3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[j] = (in >> (4 * i + j) & 1u) ? ra[i][j] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < BV; i++) {
             const int idx = t + i * 256;
             float* b = &Bs[buf][(idx / NV) * LDB_S + (idx % NV) * 4];
-            b[0] = rb[i][0]; b[1] = rb[i][1]; b[2] = rb[i][2]; b[3] = rb[i][3];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = (in >> (16 + 4 * i + j) & 1u) ? rb[i][j] : 0.f;
         }
     };
     auto compute = [&](int buf) {
@@ -138,21 +155,24 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         for (int s = 0; s < BK / 2; s++)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], b[2 * s * LDB_S], acc, 0, 0, 0);
     };
-    load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra0, rb0, row_seg);
-    if (nk > 1) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + BK, k_end, ra1, rb1, row_seg);
-    stage(0, ra0, rb0);
+    in0 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra0, rb0, row_seg);
+    if (nk > 1) in1 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + BK, k_end, ra1, rb1, row_seg);
+    stage(0, ra0, rb0, in0);
     __syncthreads();
+    // (the prefetches are unconditional: past the last tile they re-read a clamped in-range tile that is never staged -- a load
+    //  under `if (kt + 2 < nk)` into these loop-carried registers would be waited for on the spot)
+    const int k_last = k_begin + (nk - 1) * BK;      // the last real tile's k0 (aligned like every k0)
     for (int kt = 0; kt < nk; kt += 2) {
         // even tile kt lives in LDS buffer 0
-        if (kt + 2 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 2) * BK, k_end, ra0, rb0, row_seg);
+        in0 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, min(k_begin + (kt + 2) * BK, k_last), k_end, ra0, rb0, row_seg);
         compute(0);
-        if (kt + 1 < nk) stage(1, ra1, rb1);
+        if (kt + 1 < nk) stage(1, ra1, rb1, in1);
         __syncthreads();
         if (kt + 1 >= nk) break;
         // odd tile kt + 1 lives in LDS buffer 1
-        if (kt + 3 < nk) load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + (kt + 3) * BK, k_end, ra1, rb1, row_seg);
+        in1 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, min(k_begin + (kt + 3) * BK, k_last), k_end, ra1, rb1, row_seg);
         compute(1);
-        if (kt + 2 < nk) stage(0, ra0, rb0);
+        if (kt + 2 < nk) stage(0, ra0, rb0, in0);
         __syncthreads();
     }
 
@@ -168,16 +188,24 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         return;
     }
     const float bv = g.bias ? g.bias[col] : 0.f;
+    float rd[16], rs[16];                                  // clamped rows, all loads in flight before the first use
+    if (g.row_div) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) rd[r] = g.row_div[min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1)];
+    }
+    if (g.residual) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) rs[r] = g.residual[(size_t)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, g.M - 1) * g.ldr + col];
+    }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (row >= g.M) continue;
         float v = acc[r];
-        if (g.row_div) v = v / g.row_div[row];
+        if (g.row_div) v = v / rd[r];
         v += bv;
         if (g.act == 1) v = fmaxf(v, 0.f);
-        if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-        g.C[(size_t)row * g.ldc + col] = v;
+        if (g.residual) v += rs[r];
+        if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
     }
 }
 

@@ -291,17 +291,34 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
                 continue;
             }
             const float bv = g.bias ? g.bias[col] : 0.f;
+            // row_div / residual from clamped rows, eight rows' loads in flight at once (see k_gemm_x3d's epilogue; eight, not
+            // sixteen: the <2,4,..> variants sit at their 128-register launch bound)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row >= g.M) continue;
-                float v = acc[i][j][r];
-                if (g.row_div) v = v / g.row_div[row];
-                v += bv;
-                if (g.act == 1) v = fmaxf(v, 0.f);
-                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                g.C[(size_t)row * g.ldc + col] = v;
-                if (SOUT) acc[i][j][r] = v;
+            for (int h = 0; h < 2; h++) {
+                float rd[8], rs[8];
+                if (g.row_div) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { const int r = 8 * h + q; rd[q] = g.row_div[min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1)]; }
+                }
+                if (g.residual) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int r = 8 * h + q;
+                        rs[q] = g.residual[(size_t)min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1) * g.ldr + col];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int r = 8 * h + q, row = rbase + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r];
+                    if (g.row_div) v = v / rd[q];
+                    v += bv;
+                    if (g.act == 1) v = fmaxf(v, 0.f);
+                    if (g.residual) v += rs[q];
+                    if (row >= g.M) continue;
+                    g.C[(size_t)row * g.ldc + col] = v;
+                    if (SOUT) acc[i][j][r] = v;
+                }
             }
         }
 
@@ -729,18 +746,27 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
             continue;
         }
         const float bv = g.bias ? g.bias[col] : 0.f;
+        // row_div / residual come from CLAMPED rows, all sixteen loads in flight before the first use: a load under the per-lane
+        // `row < M` predicate compiles to load + s_waitcnt vmcnt(0) -- sixteen serial memory round trips per column block.
+        float rd[16], rs[16];
+        if (g.row_div) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) rd[r] = g.row_div[min(m0 + rloc + (r & 3) + 8 * (r >> 2), g.M - 1)];
+        }
+        if (g.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) rs[r] = g.residual[(size_t)min(m0 + rloc + (r & 3) + 8 * (r >> 2), g.M - 1) * g.ldr + col];
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int rl = rloc + (r & 3) + 8 * (r >> 2), row = m0 + rl;
-            float v = 0.f;
-            if (row < g.M) {
-                v = acc[j][r];
-                if (g.row_div) v = v / g.row_div[row];
-                v += bv;
-                if (g.act == 1) v = fmaxf(v, 0.f);
-                if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                g.C[(size_t)row * g.ldc + col] = v;
-            }
+            float v = acc[j][r];
+            if (g.row_div) v = v / rd[r];
+            v += bv;
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            if (g.residual) v += rs[r];
+            if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+            else v = 0.f;
             if (SOUT) T[rl * BN + j * 32 + l31] = v;
         }
     }

@@ -27,20 +27,21 @@ __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restric
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
     double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
     const float* base = x + 4 * tx;
-    for (int r = r0 + ty; r < r1; r += 4 * TR) {
+    auto add = [&](const float4& v) {
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        ss[0] += (double)v.x * v.x; ss[1] += (double)v.y * v.y; ss[2] += (double)v.z * v.z; ss[3] += (double)v.w * v.w;
+    };
+    // full groups of four rows with four unconditional loads in flight, then the tail row by row: the same rows in the same order
+    // as one guarded loop, but a guarded load (`rr < r1 ? load : 0`, even from a clamped row) is compiled to branch + load + wait
+    int r = r0 + ty;
+    for (; r + 3 * TR < r1; r += 4 * TR) {
         float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int rr = r + u * TR;
-            v[u] = rr < r1 ? *(const float4*)(base + (size_t)rr * C) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < 4; u++) v[u] = *(const float4*)(base + (size_t)(r + u * TR) * C);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w;
-            ss[0] += (double)v[u].x * v[u].x; ss[1] += (double)v[u].y * v[u].y;
-            ss[2] += (double)v[u].z * v[u].z; ss[3] += (double)v[u].w * v[u].w;
-        }
+        for (int u = 0; u < 4; u++) add(v[u]);
     }
+    for (; r < r1; r += TR) add(*(const float4*)(base + (size_t)r * C));
 #pragma unroll
     for (int j = 0; j < 4; j++) { sh[threadIdx.x * 8 + j] = s[j]; sh[threadIdx.x * 8 + 4 + j] = ss[j]; }
     __syncthreads();
@@ -126,20 +127,25 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
     const int C4 = C >> 2, TR = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {1.f, 1.f, 1.f, 1.f}, rmu[4] = {0.f, 0.f, 0.f, 0.f}, rrs[4] = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (stats) { const float2 st = stats[(size_t)b * C + 4 * tx + j]; mu[j] = st.x; rs[j] = st.y; }
-        if (res_stats) { const float2 st = res_stats[(size_t)b * C + 4 * tx + j]; rmu[j] = st.x; rrs[j] = st.y; }
+    if (stats) {
+        const float4* st = (const float4*)(stats + (size_t)b * C + 4 * tx);              // (mean, rstd) of channels 4 tx .. 4 tx + 3
+        const float4 a = st[0], c = st[1];
+        mu[0] = a.x; rs[0] = a.y; mu[1] = a.z; rs[1] = a.w; mu[2] = c.x; rs[2] = c.y; mu[3] = c.z; rs[3] = c.w;
+    }
+    if (res_stats) {
+        const float4* st = (const float4*)(res_stats + (size_t)b * C + 4 * tx);
+        const float4 a = st[0], c = st[1];
+        rmu[0] = a.x; rrs[0] = a.y; rmu[1] = a.z; rrs[1] = a.w; rmu[2] = c.x; rrs[2] = c.y; rmu[3] = c.z; rrs[3] = c.w;
     }
     for (int r = r0 + ty; r < r1; r += 4 * TR) {
+        // Loads from CLAMPED rows, unconditional: under the per-lane `rr < r1` predicate every load was followed by its own
+        // s_waitcnt vmcnt(0) (tools/isa_scan.py) -- four to eight serial round trips per iteration instead of all in flight.
         float4 v[4], rv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int rr = r + u * TR;
-            if (rr < r1) {
-                v[u] = *(const float4*)(x + (size_t)rr * C + 4 * tx);
-                if (res) rv[u] = *(const float4*)(res + (size_t)rr * C + 4 * tx);
-            }
+        for (int u = 0; u < 4; u++) v[u] = *(const float4*)(x + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
+        if (res) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) rv[u] = *(const float4*)(res + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
