@@ -53,7 +53,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 4
+#define REGTR_ABI_VERSION 5
 int regtr_abi_version(void);
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
@@ -280,6 +280,27 @@ int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
                   int precision, void* stream);
+
+/* The whole pre-norm cross-encoder stack (transformers.py:183-244 forward_pre for every layer, :37-59 the final norm of every
+ * layer's output) enqueued by one call -- the same launches, in the same order, as calling regtr_layernorm / regtr_gemm_x3 /
+ * regtr_mha_fwd layer by layer (12 per layer); it exists because at one pair per forward the host, not the GPU, is the bound.
+ *   x [n_tok, d_model] packed tokens (left untouched)  ->  outs [n_layers | 1, n_tok, d_model]
+ *   layer_params  HOST array of n_layers * regtr_cross_encoder_per_layer_params() DEVICE pointers, per layer:
+ *                 norm1 gamma, beta | self_attn in_proj planes, bias | out_proj planes, bias | norm2 gamma, beta |
+ *                 multihead_attn in_proj planes, bias | out_proj planes, bias | norm3 gamma, beta | linear1 planes, bias |
+ *                 linear2 planes, bias          (planes = regtr_gemm_split_weights of the nn.Linear weight)
+ *   layer_eps     HOST array, 3 floats per layer;  final_gamma NULL = no final LayerNorm (plain copy)
+ *   pe            [n_tok, d_model] added to the normalised tokens for q, k and v (sa/ca_val_has_pos_emb = true), or NULL
+ *   supported():  head_dim 32 and every Linear on the split kernel; otherwise issue the launches one by one.
+ *   ws            regtr_cross_encoder_ws_bytes(n_tok, d_model, d_ff) bytes */
+int regtr_cross_encoder_per_layer_params(void);
+int regtr_cross_encoder_supported(int n_tok, int d_model, int d_ff, int n_heads);
+size_t regtr_cross_encoder_ws_bytes(int n_tok, int d_model, int d_ff);
+int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, int n_heads, int n_layers,
+                            const void* const* layer_params, const float* layer_eps, const float* final_gamma,
+                            const float* final_beta, float final_eps, int return_intermediate, const float* pe,
+                            const int* seg_off, const int* kv_self, const int* kv_cross, int n_clouds, int max_len,
+                            int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, void* stream);
 
 /* CorrespondenceDecoder.simple_attention (regtr.py:316-351, `direct_regress_coor: False`): single-head attention whose values
  * are coordinates.  q, k [n_layers, n_total, head_dim] contiguous (projections of the conditioned features), xyz [n_total,3],

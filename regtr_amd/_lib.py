@@ -20,7 +20,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 4          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 5          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -72,6 +72,10 @@ SIGNATURES = {
     'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
     'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    'regtr_cross_encoder_per_layer_params': (_I, []),
+    'regtr_cross_encoder_supported': (_I, [_I, _I, _I, _I]),
+    'regtr_cross_encoder_ws_bytes': (_Z, [_I, _I, _I]),
+    'regtr_cross_encoder_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
     'regtr_attn_xyz': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
 }

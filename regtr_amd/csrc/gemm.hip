@@ -39,7 +39,7 @@ struct GemmArgs {
 // select right away, compiles to load + s_waitcnt vmcnt(0) -- the tile's loads became serial memory round trips in front of the
 // MFMAs they were meant to hide behind (tools/isa_scan.py).  mask: bit 4 i + j = element j of A vector i is inside k_end,
 // bit 16 + 4 i + j the same for B (also inside N).
-template <bool ALIGNED, int BM, int BN>
+template <bool ALIGNED_A, bool ALIGNED_B, int BM, int BN>
 __device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0, int k0, int k_end,
                                                float (&ra)[BM * BK / 1024][4], float (&rb)[BK * BN / 1024][4], const int* row_seg)
 {
@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0
     for (int i = 0; i < BM * BK / 1024; i++) {      // A: BM rows x BK k -> (row = idx / KV, k4 = (idx % KV) * 4)
         const int idx = t + i * 256;
         const int row = min(m0 + idx / KV, g.M - 1), k = k0 + (idx % KV) * 4;
-        if (ALIGNED) {                              // (k_end % 4 == 0: a float4 is wholly inside or wholly outside)
+        if (ALIGNED_A) {                            // (k_end % 4 == 0: a float4 is wholly inside or wholly outside)
             const float4 v = *(const float4*)(g.A + (size_t)row * g.lda + min(k, k_end - 4));
             ra[i][0] = v.x; ra[i][1] = v.y; ra[i][2] = v.z; ra[i][3] = v.w;
             mask |= (k < k_end ? 0xfu : 0u) << (4 * i);
@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0
         const int idx = t + i * 256;
         const int k = k0 + idx / NV, n = n0 + (idx % NV) * 4;
         const int kc = min(k, k_end - 1);
-        if (ALIGNED) {                              // (N % 4 == 0)
+        if (ALIGNED_B) {                            // (N % 4 == 0)
             const float4 v = *(const float4*)(g.B + (size_t)kc * g.ldb + min(n, g.N - 4));
             rb[i][0] = v.x; rb[i][1] = v.y; rb[i][2] = v.z; rb[i][3] = v.w;
             mask |= ((k < k_end && n < g.N) ? 0xfu : 0u) << (16 + 4 * i);
@@ -95,7 +95,8 @@ __device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0
 }
 
 // WMW x WNW waves, each a 32x32 accumulator
-template <bool ALIGNED, int WMW, int WNW>
+// ALIGNED_A / ALIGNED_B: the operand may be read as float4 (the thin head Linears -- N = 3, 1 -- still stream their A operand so)
+template <bool ALIGNED_A, bool ALIGNED_B, int WMW, int WNW>
 __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
 {
     constexpr int BM = 32 * WMW, BN = 32 * WNW, LDB_S = BN + 1;
@@ -155,8 +156,8 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
         for (int s = 0; s < BK / 2; s++)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * s], b[2 * s * LDB_S], acc, 0, 0, 0);
     };
-    in0 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin, k_end, ra0, rb0, row_seg);
-    if (nk > 1) in1 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, k_begin + BK, k_end, ra1, rb1, row_seg);
+    in0 = load_tiles<ALIGNED_A, ALIGNED_B, BM, BN>(g, m0, n0, k_begin, k_end, ra0, rb0, row_seg);
+    if (nk > 1) in1 = load_tiles<ALIGNED_A, ALIGNED_B, BM, BN>(g, m0, n0, k_begin + BK, k_end, ra1, rb1, row_seg);
     stage(0, ra0, rb0, in0);
     __syncthreads();
     // (the prefetches are unconditional: past the last tile they re-read a clamped in-range tile that is never staged -- a load
@@ -164,13 +165,13 @@ __global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
     const int k_last = k_begin + (nk - 1) * BK;      // the last real tile's k0 (aligned like every k0)
     for (int kt = 0; kt < nk; kt += 2) {
         // even tile kt lives in LDS buffer 0
-        in0 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, min(k_begin + (kt + 2) * BK, k_last), k_end, ra0, rb0, row_seg);
+        in0 = load_tiles<ALIGNED_A, ALIGNED_B, BM, BN>(g, m0, n0, min(k_begin + (kt + 2) * BK, k_last), k_end, ra0, rb0, row_seg);
         compute(0);
         if (kt + 1 < nk) stage(1, ra1, rb1, in1);
         __syncthreads();
         if (kt + 1 >= nk) break;
         // odd tile kt + 1 lives in LDS buffer 1
-        in1 = load_tiles<ALIGNED, BM, BN>(g, m0, n0, min(k_begin + (kt + 3) * BK, k_last), k_end, ra1, rb1, row_seg);
+        in1 = load_tiles<ALIGNED_A, ALIGNED_B, BM, BN>(g, m0, n0, min(k_begin + (kt + 3) * BK, k_last), k_end, ra1, rb1, row_seg);
         compute(1);
         if (kt + 2 < nk) stage(0, ra0, rb0, in0);
         __syncthreads();
@@ -266,16 +267,17 @@ int regtr_gemm_f32(const float* A, int lda, const float* B, int ldb, float* C, i
     const int S_eff = rg_cdiv(K, k_chunk);
     GemmArgs g{A, B, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off, S_eff > 1 ? (float*)ws : nullptr,
                M, N, K, lda, ldb, ldc, ldr, act, n_seg, k_chunk, a_slope};
-    const bool aligned = (K % 4 == 0) && (N % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
-                         (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (k_chunk % 4 == 0);
+    const bool aligned_a = (K % 4 == 0) && (lda % 4 == 0) && ((uintptr_t)A % 16 == 0) && (k_chunk % 4 == 0);
+    const bool aligned_b = (N % 4 == 0) && (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(rg_cdiv(M, bm), rg_cdiv(N, bn), S_eff);
     if (thin) {
-        if (aligned) k_gemm_f32<true, 4, 1><<<grid, 256, 0, st>>>(g);
-        else k_gemm_f32<false, 4, 1><<<grid, 256, 0, st>>>(g);
+        if (aligned_a && aligned_b) k_gemm_f32<true, true, 4, 1><<<grid, 256, 0, st>>>(g);
+        else if (aligned_a) k_gemm_f32<true, false, 4, 1><<<grid, 256, 0, st>>>(g);
+        else k_gemm_f32<false, false, 4, 1><<<grid, 256, 0, st>>>(g);
     } else {
-        if (aligned) k_gemm_f32<true, 2, 2><<<grid, 256, 0, st>>>(g);
-        else k_gemm_f32<false, 2, 2><<<grid, 256, 0, st>>>(g);
+        if (aligned_a && aligned_b) k_gemm_f32<true, true, 2, 2><<<grid, 256, 0, st>>>(g);
+        else k_gemm_f32<false, false, 2, 2><<<grid, 256, 0, st>>>(g);
     }
     if (S_eff > 1) k_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, S_eff);
     RG_RETURN_IF_LAUNCH_FAILED();

@@ -7,11 +7,12 @@ array with device-side segment offsets, so the shared-weight self-attention of s
 cross-attention and the FFN each become ONE launch over all tokens of the batch.
 """
 import copy
+import ctypes
 
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .kpconv import _prepared
 
 
@@ -111,17 +112,76 @@ class TransformerCrossEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList([copy.deepcopy(cross_encoder_layer) for _ in range(num_layers)])   # :268-269
         self.num_layers, self.norm, self.return_intermediate = num_layers, norm, return_intermediate
+        self._table = None
 
     def forward(self, x, pe, seg_off, kv_self, kv_cross, max_len):
         """-> (L, N_total, D) if return_intermediate else (1, N_total, D)   (transformers.py:37-59)."""
         n_out = self.num_layers if self.return_intermediate else 1
         outs = torch.empty((n_out,) + tuple(x.shape), dtype=torch.float32, device=x.device)
+        if self._one_call_ok(x, pe):
+            return self._forward_one_call(x, pe, seg_off, kv_self, kv_cross, max_len, outs)
         for li, layer in enumerate(self.layers):
             x = layer(x, pe, seg_off, kv_self, kv_cross, max_len)
             if self.return_intermediate:
                 self._final(x, outs[li])
         if not self.return_intermediate:
             self._final(x, outs[0])
+        return outs
+
+    # ---- the whole stack through ONE C call (regtr_cross_encoder_fwd): the same 12 launches per layer, sequenced in C.  At one
+    # pair per forward the host is the bound and these are 72 of its ~280 launches (csrc/cross_encoder.hip).
+    def _one_call_ok(self, x, pe):
+        l0 = self.layers[0]
+        if not (ops.use_one_call_cross_encoder and ops.mha_records is None and not ops.force_f32_gemm and x.dim() == 2 and x.is_contiguous()
+                and x.data_ptr() % 16 == 0 and (pe is None or pe.is_contiguous())):
+            return False
+        for layer in self.layers:
+            if not (layer.normalize_before and (pe is None or (layer.sa_val_has_pos_emb and layer.ca_val_has_pos_emb))
+                    and layer.gemm_planes == l0.gemm_planes and layer.attn_precision == l0.attn_precision and layer.nhead == l0.nhead
+                    and layer.linear1.out_features == l0.linear1.out_features):
+                return False
+        return bool(_lib.lib().regtr_cross_encoder_supported(x.shape[0], x.shape[1], l0.linear1.out_features, l0.nhead))
+
+    def _param_table(self):
+        """(ctypes array of the layers' device pointers in regtr_cross_encoder_fwd's order, ctypes array of the norm eps) -- rebuilt only
+        when a pointer changes; the tensors behind the pointers are kept alive by the modules / the layers' weight caches."""
+        ptrs, eps = [], []
+        for layer in self.layers:
+            m = layer._modules
+            sa, ca = m['self_attn'], m['multihead_attn']
+            n1, n2, n3, l1, l2 = m['norm1'], m['norm2'], m['norm3'], m['linear1'], m['linear2']
+            eps += [n1.eps, n2.eps, n3.eps]
+            for t in (n1.weight, n1.bias, layer._wt('sa_in', sa.in_proj_weight).planes, sa.in_proj_bias,
+                      layer._wt('sa_out', sa.out_proj.weight).planes, sa.out_proj.bias,
+                      n2.weight, n2.bias, layer._wt('ca_in', ca.in_proj_weight).planes, ca.in_proj_bias,
+                      layer._wt('ca_out', ca.out_proj.weight).planes, ca.out_proj.bias,
+                      n3.weight, n3.bias, layer._wt('l1', l1.weight).planes, l1.bias, layer._wt('l2', l2.weight).planes, l2.bias):
+                ptrs.append(t.data_ptr())
+        key = (tuple(ptrs), tuple(eps))
+        if self._table is None or self._table[0] != key:
+            for layer in self.layers:                       # checked once per table: everything the C side dereferences is float32 / bytes on one GPU
+                for prm in layer.parameters():
+                    _lib.ptr(prm.detach())
+            self._table = (key, (ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_float * len(eps))(*eps))
+        return self._table[1], self._table[2]
+
+    def _forward_one_call(self, x, pe, seg_off, kv_self, kv_cross, max_len, outs):
+        L = _lib.lib()
+        l0 = self.layers[0]
+        n, D = x.shape
+        F = l0.linear1.out_features
+        table, eps = self._param_table()
+        nb = L.regtr_cross_encoder_ws_bytes(n, D, F)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        g = b = None
+        feps = 0.0
+        if self.norm is not None:
+            g, b, feps = self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps
+        _lib.check(L.regtr_cross_encoder_fwd(_lib.ptr(x), n, D, F, l0.nhead, self.num_layers, table, eps, _lib.ptr(g), _lib.ptr(b), feps,
+                                             1 if self.return_intermediate else 0, _lib.ptr(pe), _lib.iptr(seg_off), _lib.iptr(kv_self),
+                                             _lib.iptr(kv_cross), seg_off.numel() - 1, int(max_len), int(l0.gemm_planes),
+                                             int(l0.attn_precision), _lib.bptr(ws), nb, _lib.ptr(outs), _lib.stream()),
+                   'regtr_cross_encoder_fwd')
         return outs
 
     def _final(self, x, out):
