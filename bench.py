@@ -456,6 +456,7 @@ def main():
             poses.append(out['pose'][-1])
         return (poses[0] if len(poses) == 1 else torch.cat(poses)), out
     elapsed, all_poses, all_ids, last_out = timed_passes(args, dist, lomatch, pair_ids, step, torch.cuda.synchronize, dev)
+    peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30       # inputs, weights and every buffer of the forwards so far
     assert all_poses.shape[0] == pairs_per_step and torch.isfinite(all_poses).all()
     ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)                                      # who entered the all_gather
     assert ranks_seen == world, (ranks_seen, world)
@@ -484,7 +485,7 @@ def main():
             'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'fp32x3': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
                        'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
-                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather'},
+                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather', 'peak_hbm_allocated_GiB': round(peak_gb, 2)},
         }
         if args.parity_pairs > 0:
             # "pose err vs ref" (BASELINE.json metric): the last timed forward's outputs against the CPU oracle, >= 2 pairs

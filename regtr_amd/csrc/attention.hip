@@ -287,6 +287,13 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) f_off[ks] = (unsigned)l31 * BROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
 
+// development A-B (variant build -DMHA_SETPRIO=1): raise the wave's issue priority around its MFMA groups, the explicit form of the
+// MFMA / VALU "ping-pong" between the 3 waves a SIMD holds.  Measured: see the kernel's header comment.
+#ifdef MHA_SETPRIO
+#define MHA_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define MHA_PRIO(p)
+#endif
 #ifdef MHA_PROF          // development: per-wave phase clocks (REGTR_VARIANT_FLAGS=-DMHA_PROF)
     long long pt[6] = {0, 0, 0, 0, 0, 0}, pc = clock64(), pstart = pc;
 #define MHA_STAMP(I) do { const long long n_ = clock64(); pt[I] += n_ - pc; pc = n_; } while (0)
@@ -315,7 +322,9 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
                 bf16x8 kf[NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) kf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Ks[buf][p][f_off[ks]]));
+                MHA_PRIO(2);
                 sc = bf_mma<NP>(kf, qf[ks], sc);
+                MHA_PRIO(0);
             }
             MHA_STAMP(2);
             float mx = -INFINITY;
@@ -348,7 +357,9 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
                 bf_split8<NP>(x, pf);
 #pragma unroll
                 for (int p = 0; p < NP; p++) vf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Vt[buf][p][f_off[ks]]));
+                MHA_PRIO(2);
                 o = bf_mma<NP>(vf, pf, o);
+                MHA_PRIO(0);
             }
             MHA_STAMP(3);
         }

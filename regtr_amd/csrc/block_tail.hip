@@ -39,7 +39,7 @@ template <int KC, bool INFOLD, bool ROWDIV>      // K = 32 KC
 __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* __restrict__ A, int lda, const float2* __restrict__ stats,
                                                                float slope, const float* __restrict__ row_div, int k_valid,
                                                                const int* __restrict__ seg_off, int n_chunks,
-                                                               double* __restrict__ partial)
+                                                               double* __restrict__ partial, float* __restrict__ pivot)
 {
     constexpr int K = 32 * KC, NTILE = KC * (KC + 1) / 2;
     __shared__ double red[K * K + K];
@@ -57,6 +57,22 @@ __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* _
     for (int c = 0; c < KC; c++) {
         mu[c] = 0.f; rs[c] = 1.f;
         if (INFOLD) { const float2 s = stats[(size_t)cloud * K + 32 * c + chc]; mu[c] = s.x; rs[c] = s.y; }
+    }
+    // The moments are those of x - pivot, pivot = the cloud's FIRST row (every wave and chunk of the cloud loads the same one):
+    // covariances do not change under a shift, and the float32 rounding of the sums (~1e-6 of sum x^2) then scales with the spread
+    // of a channel instead of with its mean^2 -- a near-constant channel (variance << mean^2) would otherwise lose its variance
+    // to that rounding.  k_tail_prepare adds the pivot back to the means.
+    float pv[KC];
+    {
+        const int r0 = seg_off[cloud];
+        const float d0 = ROWDIV ? row_div[r0] : 1.f;
+#pragma unroll
+        for (int c = 0; c < KC; c++) {
+            float v = A[(size_t)r0 * lda + 32 * c + chc];
+            if (ROWDIV) v = v / d0;
+            if (INFOLD) { const float u = (v - mu[c]) * rs[c]; v = fmaxf(u, u * slope); }
+            pv[c] = ch_ok ? v : 0.f;
+        }
     }
     // float32 accumulation over the wave's <= 512 rows (rounding ~1e-6 of a sum, independent between the ~40 waves of a cloud),
     // float64 from there on; per-64-row float64 accumulators cost 96 registers and a third of the occupancy
@@ -93,7 +109,7 @@ __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* _
                 float v = xv[s][c];
                 if (ROWDIV) v = v / dv[ROWDIV ? s : 0];
                 if (INFOLD) { const float u = (v - mu[c]) * rs[c]; v = fmaxf(u, u * slope); }
-                x[c] = ok ? v : 0.f;
+                x[c] = ok ? v - pv[c] : 0.f;
                 s1[c] += x[c];
             }
             int t = 0;
@@ -141,6 +157,10 @@ __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* _
         if (i < kv * kv) { const int a = i / kv, b = i - a * kv; src = a * K + b; }
         out[i] = red[src];
     }
+    if (chunk == 0 && wave == 0 && half == 0 && ch_ok) {
+#pragma unroll
+        for (int c = 0; c < KC; c++) pivot[(size_t)cloud * kv + 32 * c + ch] = pv[c];
+    }
 }
 
 __device__ __forceinline__ unsigned bt_pack(float a, float b)
@@ -164,7 +184,7 @@ template <int K>
 __device__ void bt_prepare_source(const double* __restrict__ partial, int n_chunks_total, int n_valid, int n_rows, int cloud,
                                   const float* __restrict__ W_kn, int N, int col0, float eps, double* cov /*LDS [K*K + K]*/,
                                   double2* quad /*LDS [256]*/, uint16_t* __restrict__ planes, float* __restrict__ in_mean,
-                                  float2* __restrict__ out_stats)
+                                  float2* __restrict__ out_stats, const float* __restrict__ pivot)
 {
     const double inv_n = 1.0 / (double)n_rows;
     for (int i = threadIdx.x; i < K * K + K; i += blockDim.x) {
@@ -178,11 +198,15 @@ __device__ void bt_prepare_source(const double* __restrict__ partial, int n_chun
         cov[i] = s * inv_n;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {          // centred second moments
+    for (int i = threadIdx.x; i < K * K; i += blockDim.x) {          // centred second moments (of x - pivot: the same as of x)
         const int a = i / K, b = i - a * K;
         cov[i] -= cov[K * K + a] * cov[K * K + b];
     }
-    if (col0 == 0 && threadIdx.x < K) in_mean[(size_t)cloud * K + threadIdx.x] = (float)cov[K * K + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < K) {                                           // mean(x) = pivot + mean(x - pivot)
+        cov[K * K + threadIdx.x] += (double)pivot[(size_t)cloud * K + threadIdx.x];
+        if (col0 == 0) in_mean[(size_t)cloud * K + threadIdx.x] = (float)cov[K * K + threadIdx.x];
+    }
     __syncthreads();
     const int j = col0 + (threadIdx.x & 63), h = threadIdx.x >> 6;   // column, row quarter (= wave)
     float wj[K];                                                     // the column of W, once (coalesced across the threads)
@@ -226,7 +250,8 @@ __global__ void __launch_bounds__(256) k_tail_prepare(const double* __restrict__
                                                       const int* __restrict__ seg_off, int n_chunks, const float* __restrict__ W1,
                                                       const float* __restrict__ W2, int N, float eps, uint16_t* __restrict__ planes1,
                                                       uint16_t* __restrict__ planes2, float* __restrict__ mean1,
-                                                      float* __restrict__ mean2, float2* __restrict__ out_stats, int n_clouds)
+                                                      float* __restrict__ mean2, float2* __restrict__ out_stats, int n_clouds,
+                                                      const float* __restrict__ pivot1, const float* __restrict__ pivot2)
 {
     constexpr int KM = K1 > K2 ? K1 : K2;
     __shared__ double cov[KM * KM + KM];
@@ -235,10 +260,10 @@ __global__ void __launch_bounds__(256) k_tail_prepare(const double* __restrict__
     const int n = seg_off[cloud + 1] - seg_off[cloud];
     if (n <= 0) return;                                              // no row of this cloud reaches k_tail_strip
     const int n_valid = (n + MO_ROWS_WG - 1) / MO_ROWS_WG;
-    bt_prepare_source<K1>(part1, n_chunks, n_valid, n, cloud, W1, N, col0, eps, cov, quad, planes1, mean1, out_stats);
+    bt_prepare_source<K1>(part1, n_chunks, n_valid, n, cloud, W1, N, col0, eps, cov, quad, planes1, mean1, out_stats, pivot1);
     if constexpr (K2 > 0)
         bt_prepare_source<K2>(part2, n_chunks, n_valid, n, cloud, W2, N, col0, eps, cov, quad, planes2, mean2,
-                              out_stats ? out_stats + (size_t)n_clouds * N : nullptr);
+                              out_stats ? out_stats + (size_t)n_clouds * N : nullptr, pivot2);
 }
 
 // ------------------------------------------------------------------------------------------------------------------ the strip
@@ -453,7 +478,7 @@ size_t bt_res_ws_bytes(int n_clouds, int max_len, int N, int K1)
 {
     const size_t nc = (size_t)bt_chunks(max_len);
     return ((n_clouds * nc * (K1 * K1 + K1) * 8 + 255) & ~(size_t)255) + (((size_t)n_clouds * 3 * N * K1 * 2 + 255) & ~(size_t)255) +
-           (((size_t)n_clouds * K1 * 4 + 255) & ~(size_t)255);
+           2 * (((size_t)n_clouds * K1 * 4 + 255) & ~(size_t)255);
 }
 size_t bt_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
@@ -476,7 +501,7 @@ size_t regtr_block_tail_ws_bytes(int n_clouds, int max_len, int N, int K1, int K
     const size_t nc = (size_t)bt_chunks(max_len);
     return bt_align(n_clouds * nc * (K1 * K1 + K1) * 8) + bt_align(n_clouds * nc * (K2 * K2 + K2) * 8) +
            bt_align((size_t)n_clouds * 3 * N * K1 * 2) + bt_align((size_t)n_clouds * 3 * N * K2 * 2) +
-           bt_align((size_t)n_clouds * K1 * 4) + bt_align((size_t)n_clouds * K2 * 4);
+           2 * (bt_align((size_t)n_clouds * K1 * 4) + bt_align((size_t)n_clouds * K2 * 4));
 }
 
 // Y[M, N] = LeakyReLU_slope( InstanceNorm(A1' W1) [+ InstanceNorm(A2 W2)] )
@@ -503,23 +528,25 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
     uint16_t* planes1 = (uint16_t*)p; p += bt_align((size_t)n_clouds * 3 * N * K1 * 2);
     uint16_t* planes2 = (uint16_t*)p; p += bt_align((size_t)n_clouds * 3 * N * K2 * 2);
     float* mean1 = (float*)p; p += bt_align((size_t)n_clouds * K1 * 4);
-    float* mean2 = (float*)p;
+    float* mean2 = (float*)p; p += bt_align((size_t)n_clouds * K2 * 4);
+    float* pivot1 = (float*)p; p += bt_align((size_t)n_clouds * K1 * 4);
+    float* pivot2 = (float*)p;
     hipStream_t st = (hipStream_t)stream;
     const dim3 mgrid(nc, n_clouds), pgrid(n_clouds, N / 64), sgrid(rg_cdiv(M, TS_ROWS), 1);
     TailArgs g{A1, A2, Y, (const float2*)a1_stats, row_div1, mean1, mean2, planes1, planes2, seg_off, (const int4*)tile_info,
                M, N, lda1, lda2, ldy, n_clouds, a1_slope, slope, nullptr, nullptr, 0};
     const size_t lds = (size_t)3 * N * (K1 + K2) * 2;                // the workgroup holds all N columns
     if (K2 > 0) {
-        k_moments<1, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1);
-        k_moments<2, false, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A2, lda2, nullptr, 0.f, nullptr, K2, seg_off, nc, part2);
+        k_moments<1, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1, pivot1);
+        k_moments<2, false, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A2, lda2, nullptr, 0.f, nullptr, K2, seg_off, nc, part2, pivot2);
         k_tail_prepare<32, 64><<<pgrid, 256, 0, st>>>(part1, part2, seg_off, nc, W1, W2, N, eps, planes1, planes2, mean1, mean2,
-                                                      (float2*)out_stats, n_clouds);
+                                                      (float2*)out_stats, n_clouds, pivot1, pivot2);
         if (!rg_allow_dynamic_lds<k_tail_strip<2, 4, 2, 2, true>>(lds)) return RG_ERR_ARG;
         k_tail_strip<2, 4, 2, 2, true><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
     } else {
-        k_moments<1, false, true><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, nullptr, 0.f, row_div1, K1, seg_off, nc, part1);
+        k_moments<1, false, true><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, nullptr, 0.f, row_div1, K1, seg_off, nc, part1, pivot1);
         k_tail_prepare<16, 0><<<pgrid, 256, 0, st>>>(part1, nullptr, seg_off, nc, W1, nullptr, N, eps, planes1, nullptr, mean1, nullptr,
-                                                     (float2*)out_stats, n_clouds);
+                                                     (float2*)out_stats, n_clouds, pivot1, nullptr);
         if (!rg_allow_dynamic_lds<k_tail_strip<1, 0, 2, 1, false>>(lds)) return RG_ERR_ARG;
         k_tail_strip<1, 0, 2, 1, false><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);
     }
@@ -555,7 +582,8 @@ int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float
     unsigned char* p = (unsigned char*)ws;
     double* part1 = (double*)p; p += bt_align((size_t)n_clouds * nc * (K1 * K1 + K1) * 8);
     uint16_t* planes1 = (uint16_t*)p; p += bt_align((size_t)n_clouds * 3 * N * K1 * 2);
-    float* mean1 = (float*)p;
+    float* mean1 = (float*)p; p += bt_align((size_t)n_clouds * K1 * 4);
+    float* pivot1 = (float*)p;
     hipStream_t st = (hipStream_t)stream;
     const bool wide = N % 256 == 0;                                  // a workgroup holds 256 (else 64) columns of the cloud's planes: A is read once
     const int nbw = wide ? 256 : 64;
@@ -563,8 +591,9 @@ int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float
     TailArgs g{A1, nullptr, Y, (const float2*)a1_stats, nullptr, mean1, nullptr, planes1, nullptr, seg_off, (const int4*)tile_info,
                M, N, lda1, 0, ldy, n_clouds, a1_slope, slope, R, (const float2*)r_stats, ldr};
     const size_t lds = (size_t)3 * nbw * K1 * 2;
-    k_moments<2, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1);
-    k_tail_prepare<64, 0><<<pgrid, 256, 0, st>>>(part1, nullptr, seg_off, nc, W1, nullptr, N, eps, planes1, nullptr, mean1, nullptr, nullptr, n_clouds);
+    k_moments<2, true, false><<<mgrid, MO_WAVES * RG_WAVE, 0, st>>>(A1, lda1, (const float2*)a1_stats, a1_slope, nullptr, K1, seg_off, nc, part1, pivot1);
+    k_tail_prepare<64, 0><<<pgrid, 256, 0, st>>>(part1, nullptr, seg_off, nc, W1, nullptr, N, eps, planes1, nullptr, mean1, nullptr, nullptr, n_clouds,
+                                                 pivot1, nullptr);
     if (wide) {
         if (!rg_allow_dynamic_lds<k_tail_strip<4, 0, 4, 2, true, true>>(lds)) return RG_ERR_ARG;
         k_tail_strip<4, 0, 4, 2, true, true><<<sgrid, TS_WAVES * RG_WAVE, lds, st>>>(g);

@@ -114,6 +114,36 @@ __global__ void __launch_bounds__(256) k_instnorm_finalize_tiles(const double2* 
     stats[(size_t)b * C + c] = make_float2(mean, rstd);
 }
 
+// The same table for SMALL cloud sets (a pair or two per forward): one WAVE per (cloud, channel), the cloud's slots dealt to the
+// lanes and added by a fixed shuffle tree.  With two clouds the thread-per-channel form above is a handful of workgroups walking
+// up to ~300 slots one dependent load after another (31 us for a 20k-point cloud at 128-row tiles, most of a one-pair forward's
+// InstanceNorm time); here that is five loads per lane.  Deterministic like the other form, but a different summation order: which
+// of the two runs depends on the launch geometry only (n_clouds * C), never on the data.
+__global__ void __launch_bounds__(256) k_instnorm_finalize_tiles_wave(const double2* __restrict__ partial, const int* __restrict__ seg_off,
+                                                                      int C, int tile_rows, float eps, float2* __restrict__ stats)
+{
+    const int b = blockIdx.y, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const int lane = rg_lane();
+    const int r0 = seg_off[b], r1 = seg_off[b + 1], n = r1 - r0;
+    float mean = 0.f, rstd = 0.f;
+    if (n > 0) {                                                      // (wave-uniform)
+        const int t0 = r0 / tile_rows, t1 = (r1 - 1) / tile_rows;
+        double s = 0, ss = 0;
+        for (int t = t0 + lane; t <= t1; t += RG_WAVE) {
+            const double2 a = partial[(size_t)(t + b) * C + c];
+            s += a.x; ss += a.y;
+        }
+        s = rg_wave_sum(s); ss = rg_wave_sum(ss);
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0) var = 0;
+        mean = (float)m;
+        rstd = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (lane == 0) stats[(size_t)b * C + c] = make_float2(mean, rstd);
+}
+
 // y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
 __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
                                                         const float2* __restrict__ stats, const float* __restrict__ res,
@@ -262,9 +292,14 @@ int regtr_instnorm_finalize_tiles(const double* partial, const int* seg_off, int
                                   float* stats, void* stream)
 {
     if (!partial || !seg_off || !stats || n_clouds < 1 || C < 1 || tile_rows < 1) return RG_ERR_ARG;
-    const int bs = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
-    k_instnorm_finalize_tiles<<<dim3(rg_cdiv(C, bs), n_clouds), bs, 0, (hipStream_t)stream>>>(
-        (const double2*)partial, seg_off, C, tile_rows, eps, (float2*)stats);
+    if ((long long)n_clouds * C <= 4096) {          // a pair or two per forward: few, long slot lists -- a wave per (cloud, channel)
+        k_instnorm_finalize_tiles_wave<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, (hipStream_t)stream>>>(
+            (const double2*)partial, seg_off, C, tile_rows, eps, (float2*)stats);
+    } else {
+        const int bs = C >= 256 ? 256 : (C >= 128 ? 128 : 64);
+        k_instnorm_finalize_tiles<<<dim3(rg_cdiv(C, bs), n_clouds), bs, 0, (hipStream_t)stream>>>(
+            (const double2*)partial, seg_off, C, tile_rows, eps, (float2*)stats);
+    }
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
