@@ -287,8 +287,12 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) f_off[ks] = (unsigned)l31 * BROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
 
-// development A-B (variant build -DMHA_SETPRIO=1): raise the wave's issue priority around its MFMA groups, the explicit form of the
-// MFMA / VALU "ping-pong" between the 3 waves a SIMD holds.  Measured: see the kernel's header comment.
+// development A-B (variant build -DMHA_SETPRIO=1): raise the wave's issue priority around its MFMA groups -- the explicit form of the
+// MFMA / VALU "ping-pong" between the 3 waves a SIMD holds (144 VGPRs + 16 AGPRs, 24 KB of LDS per workgroup: three workgroups per CU,
+// so the hardware already interleaves one wave's MFMAs with its neighbours' softmax).  Measured on a 64-pair forward, alternating
+// runs on one box: 165 us per launch against 155-156 us without (gpurun_out/r03_y4): the kernel is VALU-bound (per 32-key tile and
+// wave 768 matrix-pipe cycles against ~1500 of softmax / split arithmetic + ~900 of K/V split and staging), and prioritising the
+// pipe that has slack delays the one that has none.  Off.
 #ifdef MHA_SETPRIO
 #define MHA_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #else
