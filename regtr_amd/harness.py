@@ -9,6 +9,7 @@ GenericRegModel.test_step / _save_3DMatch_log (models/generic_reg_model.py:130-1
   * `est.log` blocks / `pred_transforms.npy` in the reference's exact formats, so the reference's own evaluation scripts
     (benchmark_predator / RPMNet eval) read them unchanged.
 """
+import json
 import os
 import pickle
 import queue
@@ -123,6 +124,13 @@ def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank
     src = SyntheticPairs(n, points, overlap=overlap)
     t0 = time.perf_counter()
     os.makedirs(root, exist_ok=True)
+    path = os.path.join(root, f'test_info.rank{rank}.pkl')
+    stamp = os.path.join(root, f'complete.rank{rank}.json')           # written last: (n, points, overlap, world) of a finished set
+    want = json.dumps([n, points, overlap, world])
+    if world == 1 and os.path.exists(stamp) and open(stamp).read() == want and os.path.exists(path):
+        if logger:
+            logger.info(f'{n} synthetic pairs already materialised under {root}')
+        return path
     poses = {}
     for i in range(rank, n, world):
         it = src[i]
@@ -144,9 +152,10 @@ def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank
         sp, tp = _synthetic_paths(src, i)
         infos['rot'].append(poses[i][:, :3].astype(np.float64)); infos['trans'].append(poses[i][:, 3:].astype(np.float64))
         infos['src'].append(sp); infos['tgt'].append(tp); infos['overlap'].append(0.0)
-    path = os.path.join(root, f'test_info.rank{rank}.pkl')
     with open(path, 'wb') as f:
         pickle.dump(infos, f)
+    with open(stamp, 'w') as f:
+        f.write(want)
     if logger:
         logger.info(f'{n} synthetic pairs materialised under {root} in {time.perf_counter() - t0:.1f} s')
     return path
