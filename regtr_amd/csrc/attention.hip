@@ -33,15 +33,22 @@ struct MhaArgs {
 // accumulator register r of half-wave `hi` holds matrix row  (r & 3) + 8 * (r >> 2) + 4 * hi
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
+// KS = key splits: KS waves per workgroup share ONE 32-query tile, wave w streaming key tiles w, w + KS, ... with its own running
+// (max, sum, O) and its own LDS tiles; the partial results are merged through LDS in wave order (flash-decoding style).  KS = 4 is the
+// launcher's choice for a pair or two per forward, where a launch is only ~200 single-wave workgroups and its duration is one wave's
+// serial walk over all keys: 32 -> 13 us per launch at one 3DMatch pair, twelve launches per forward.
+template <int KS>
+__global__ void __launch_bounds__(KS * RG_WAVE) k_mha_fwd(MhaArgs g)
 {
-    __shared__ float Ks[TK * LDS_STRIDE];
-    __shared__ float Vs[TK * LDS_STRIDE];
-    const int lane = threadIdx.x, l31 = lane & 31, hi = lane >> 5;
+    __shared__ float KVs[KS][2 * TK * LDS_STRIDE];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* Ks = KVs[wave];
+    float* Vs = KVs[wave] + TK * LDS_STRIDE;
     const int cloud = blockIdx.z, head = blockIdx.y;
     const int q_begin = g.seg_off[cloud], q_end = g.seg_off[cloud + 1];
     const int q0 = q_begin + blockIdx.x * TQ;
-    if (q0 >= q_end) return;
+    if (q0 >= q_end) return;                                        // (workgroup-uniform)
     const int kc = g.kv_of[cloud];
     const int k_begin = g.seg_off[kc], nk = g.seg_off[kc + 1] - k_begin;
     const int hoff = head * HD;
@@ -76,9 +83,10 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
             vreg[it] = *(const float4*)(g.v + (size_t)(kb + krow) * g.ldv + hoff + c4);
         }
     };
-    fetch(0);
-    for (int kt = 0; kt < nk; kt += TK) {
-        __syncthreads();
+    // (the tiles are private to the wave: wave-level barriers order its LDS writes and reads; the waves' trip counts differ)
+    fetch(wave * TK);
+    for (int kt = wave * TK; kt < nk; kt += KS * TK) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int row = it * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -87,8 +95,8 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
             float* vd = &Vs[row * LDS_STRIDE + c4];
             vd[0] = vreg[it].x; vd[1] = vreg[it].y; vd[2] = vreg[it].z; vd[3] = vreg[it].w;
         }
-        __syncthreads();
-        fetch(kt + TK);                  // unconditional: rows are clamped
+        __builtin_amdgcn_wave_barrier();
+        fetch(kt + KS * TK);             // unconditional: rows are clamped
 
         // S^T tile: rows = keys, cols = queries
         floatx16 sc;
@@ -124,6 +132,33 @@ __global__ void __launch_bounds__(RG_WAVE) k_mha_fwd(MhaArgs g)
 #pragma unroll
         for (int s = 0; s < 16; s++)
             o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[acc_row(s, hi) * LDS_STRIDE + l31], sc[s], o, 0, 0, 0);
+    }
+
+    if (KS > 1) {
+        // merge the waves' partial (m, l, O) in wave order: m = max m_w, l = sum l_w e^(m_w - m), O = sum O_w e^(m_w - m).  A wave
+        // that saw no key carries m = -inf, l = 0, O = 0 and is skipped (e^(-inf - (-inf)) would be NaN).
+        __builtin_amdgcn_wave_barrier();
+        float* mine = KVs[wave];                                    // [16][64] O | [64] m | [64] l : 4608 B of the wave's 8448
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) mine[r * 64 + lane] = o[r];
+            mine[16 * 64 + lane] = m_run;
+            mine[17 * 64 + lane] = l_run;
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll 1
+        for (int w = 1; w < KS; w++) {
+            const float* p = KVs[w];
+            const float mw = p[16 * 64 + lane], lw = p[17 * 64 + lane];
+            if (mw == -INFINITY) continue;                          // (per lane: both halves of a query column agree)
+            const float m_new = fmaxf(m_run, mw);
+            const float a0 = expf(m_run - m_new), a1 = expf(mw - m_new);          // m_run = -inf: a0 = 0, o and l_run are 0 anyway
+            l_run = l_run * a0 + lw * a1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[r] = o[r] * a0 + p[r * 64 + lane] * a1;
+            m_run = m_new;
+        }
     }
 
     const int qrow = q0 + l31;
@@ -432,28 +467,43 @@ __global__ void __launch_bounds__(RG_WAVE) k_attn_xyz(AttnXyzArgs g)
     {
         const int qrow = q0 + l31;
         const bool live = qrow < q_end;
+        // branch free (clamped row, scale 0 for a dead lane): `live ? load : 0` compiles to a load + full wait per element
+        const float* qp = Q + (size_t)(live ? qrow : q_begin) * HDX + hi;
+        const float scl = live ? g.scale : 0.f;
 #pragma unroll
-        for (int s = 0; s < HDX / 2; s++) qreg[s] = live ? Q[(size_t)qrow * HDX + 2 * s + hi] * g.scale : 0.f;
+        for (int s = 0; s < HDX / 2; s++) qreg[s] = qp[2 * s] * scl;
     }
     floatx16 o;
 #pragma unroll
     for (int r = 0; r < 16; r++) o[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    for (int e = lane; e < TK * LDS_STRIDE; e += RG_WAVE) Vs[e] = 0.f;      // columns >= 3 stay zero for the whole kernel
 
+    // Key rows and coordinates come from CLAMPED rows with no predicate, eight rows' loads in flight (keys past nk are masked to
+    // -inf below, so their finite clamped values meet p = 0); lanes beyond the row's HDX floats re-read its last float4 and store nothing.
+    constexpr int LPR = HDX / 4 < RG_WAVE ? HDX / 4 : RG_WAVE;        // lanes that own a float4 of a key row
+    const int c4 = (lane < LPR ? lane : LPR - 1) * 4;
+    const int nk1 = nk > 0 ? nk - 1 : 0;
+    const int kb = nk > 0 ? k_begin : q_begin;                        // an empty key cloud: read (and mask) rows of the query cloud
     for (int kt = 0; kt < nk; kt += TK) {
         __syncthreads();
-        for (int row = 0; row < TK; row++) {          // one key row (HDX floats) per pass: 64 lanes x 4 floats
-            const bool live = kt + row < nk;
-            for (int c4 = lane * 4; c4 < HDX; c4 += RG_WAVE * 4) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live) v = *(const float4*)(K + (size_t)(k_begin + kt + row) * HDX + c4);
-                float* kd = &Ks[row * KS + c4];
-                kd[0] = v.x; kd[1] = v.y; kd[2] = v.z; kd[3] = v.w;
+#pragma unroll 1
+        for (int row0 = 0; row0 < TK; row0 += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = *(const float4*)(K + (size_t)(kb + min(kt + row0 + i, nk1)) * HDX + c4);
+            if (lane < LPR) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    float* kd = &Ks[(row0 + i) * KS + c4];
+                    kd[0] = v[i].x; kd[1] = v[i].y; kd[2] = v[i].z; kd[3] = v[i].w;
+                }
             }
         }
-        for (int e = lane; e < TK * LDS_STRIDE; e += RG_WAVE) {
-            const int row = e / LDS_STRIDE, d = e - row * LDS_STRIDE;
-            Vs[e] = (d < 3 && kt + row < nk) ? g.xyz[(size_t)(k_begin + kt + row) * 3 + d] : 0.f;
+        {
+            const float* xp = g.xyz + (size_t)(kb + min(kt + l31, nk1)) * 3;
+            const float x = xp[0], y = xp[1], z = xp[2];
+            if (hi == 0) { Vs[l31 * LDS_STRIDE] = x; Vs[l31 * LDS_STRIDE + 1] = y; Vs[l31 * LDS_STRIDE + 2] = z; }
         }
         __syncthreads();
 
@@ -520,7 +570,12 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
     // four times as many workgroups on the chip and stages K / V without the split -- 32 us against 56 us per launch at one
     // 3DMatch pair.  Both are float32-grade, so precision 0 may take either.
     const bool small = (long long)rg_cdiv(max_len, BW * TQ) * n_heads * n_clouds < 512;
-    if (precision == 2 || (precision == 0 && small)) k_mha_fwd<<<dim3(rg_cdiv(max_len, TQ), n_heads, n_clouds), RG_WAVE, 0, st>>>(g);
+    if (precision == 2 || (precision == 0 && small)) {
+        const dim3 grid(rg_cdiv(max_len, TQ), n_heads, n_clouds);
+        // very small launches (one pair: ~200 query tiles on 256 CUs): four waves split the keys of a tile
+        if ((long long)grid.x * grid.y * grid.z <= 1024 && max_len > 4 * TK) k_mha_fwd<4><<<grid, 4 * RG_WAVE, 0, st>>>(g);
+        else k_mha_fwd<1><<<grid, RG_WAVE, 0, st>>>(g);
+    }
     else {
         if ((ldv % 2) || ((uintptr_t)v % 8)) return RG_ERR_ARG;
         const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);

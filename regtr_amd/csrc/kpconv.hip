@@ -51,6 +51,7 @@ struct GatherArgs {
     const float2* x_stats; const int* q_seg_off;     // optional fused lrelu(InstanceNorm(x)) on the gathered features
     int nq, ns, H, Cin, KP, n_seg, ld_wf;
     float extent, slope;
+    int qpw;      // k_kpconv_gather_mfma: queries each wave handles one after another (<= MG_QPW; fewer on small launches)
 };
 
 // LQ = lanes per query (16, 32 or 64); a wave handles 64 / LQ queries at a time.
@@ -294,7 +295,8 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     // basic blocks, and hipcc drains every outstanding load (s_waitcnt vmcnt(0)) at block boundaries, serialising the
     // prefetch.
     // XCD-aware: each XCD (own L2) takes one contiguous eighth of the queries -- neighbouring queries gather the same rows
-    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * MG_QPW;
+    const int qpw = g.qpw;
+    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * qpw;
     if (qbase >= nq) return;
     const int hl = lane < H ? lane : H - 1;
     auto load_idx = [&](int q) -> int {
@@ -328,7 +330,7 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     int idx_nxt = load_idx(qbase + 1);
     int seg_cur = 0, seg_end = -1;      // cloud of the current query and its end row (x_stats path)
 #pragma unroll 1
-    for (int qq = 0; qq < MG_QPW; qq++) {
+    for (int qq = 0; qq < qpw; qq++) {
         const int q = qbase + qq;
         if (q >= nq) return;            // wave-uniform
         __builtin_amdgcn_wave_barrier();
@@ -781,7 +783,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     if (!flag && !regtr_kpconv_gather_computes_flag(Cin, H)) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
     GatherArgs g{q_xyz, s_xyz, nbr, x, flag, s_xyzf, kernel_points, wf, num, (const float2*)x_stats, q_seg_off,
-                 nq, ns, H, Cin, KP, n_seg, ld_wf, extent, slope};
+                 nq, ns, H, Cin, KP, n_seg, ld_wf, extent, slope, MG_QPW};
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 1) {
         if (x_stats) return RG_ERR_ARG;
@@ -793,7 +795,13 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     const bool aligned16 = (((uintptr_t)x | (uintptr_t)wf | (uintptr_t)x_stats) & 15) == 0;
     if (!flag && !(aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29))) return RG_ERR_ARG;
     if (regtr_kpconv_gather_computes_flag(Cin, H) && aligned16 && ns > 0 && (long long)ns * Cin < (1LL << 29)) {   // matrix-core path
-        const int grid_m = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * MG_QPW));
+        // queries per wave: MG_QPW (8) on large levels (the software pipeline over a wave's queries hides the idx -> xyz -> rows chain);
+        // a small level (one pair: ~5000 queries at level 1) would be ~150 workgroups of 32 serial-ish queries on 256 CUs, so it gets
+        // as few per wave as still puts ~12 waves on every CU
+        int qpw = (int)(((long long)nq + 256 * 12 - 1) / (256 * 12));
+        qpw = qpw < 1 ? 1 : (qpw > MG_QPW ? MG_QPW : qpw);
+        g.qpw = qpw;
+        const int grid_m = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * qpw));
         const int J = H <= 40 ? 10 : (H <= 52 ? 13 : 16);
         const bool v4 = Cin % 64 == 0;
         const bool pre = s_xyzf != nullptr;
