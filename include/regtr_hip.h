@@ -204,6 +204,8 @@ int regtr_gemm_x3_preferred(int M, int N, int K);   /* supported AND measured fa
 size_t regtr_gemm_split_weights_bytes(int N, int K);
 int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
+/* diagnostic: resident workgroups per CU of the row-strip split kernel (cw 2|4 column blocks, ar 2|3|4 A-ring mode, stats epilogue) */
+int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats);
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,

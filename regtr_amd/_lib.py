@@ -52,6 +52,7 @@ SIGNATURES = {
     'regtr_gemm_split_weights_bytes': (_Z, [_I, _I]),
     'regtr_gemm_split_weights': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'regtr_gemm_x3_ws_bytes': (_Z, [_I, _I, _I]),
+    'regtr_gemm_x3_strip_occupancy': (_I, [_I, _I, _I]),
     'regtr_gemm_x3': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P, _P, _I, _I, _P, _P]),
     'regtr_tile_segments': (_I, [_P, _I, _I, _I, _P, _P]),
     'regtr_gemm_x3_tile_rows': (_I, [_I, _I, _I]),

@@ -443,9 +443,13 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     constexpr int A_BYTES = BM * XBK * 4;                      // raw float32 rows of one k-tile: 128 bytes per row
     constexpr int B_BYTES = NP * BN * XROW;
     constexpr int NQ = B_BYTES / 1024 / MW, NA = 4;            // LDS-DMA instructions (1 KiB) per wave and k-tile: weights / own A rows
-    constexpr int A_RING = AR * A_BYTES, LDS_BYTES = A_RING + 2 * B_BYTES;
+    // AR = 4: the INTERLEAVED schedule -- two A slots, A two tiles ahead, every LDS-DMA instruction issued between MFMAs (see the hand loop)
+    constexpr bool IL = AR == 4;
+    constexpr int A_SLOTS = AR == 3 ? 3 : 2;
+    constexpr int A_RING = A_SLOTS * A_BYTES, LDS_BYTES = A_RING + 2 * B_BYTES;
     static_assert(NQ * 1024 * MW == B_BYTES && NQ >= 1, "the weight tile must split evenly over the waves");
-    static_assert(AR == 2 || AR == 3, "A ring depth");
+    static_assert(AR == 2 || AR == 3 || AR == 4, "A ring mode");
+    static_assert(!IL || (NP == 3 && X3D_HAND), "the interleaved schedule exists in the hand-scheduled loop only");
     __shared__ __align__(1024) unsigned char sm[LDS_BYTES];   // [A ring: AR x BM rows x 128 B][weight ring: 2 x NP planes x BN x 64 B]
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -535,7 +539,7 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
         va[ks][0] = lds_base + A_BYTES + fa_off[ks][0];
         va[ks][1] = lds_base + A_BYTES + fa_off[ks][1];
     }
-    unsigned b_slot = 1, a_slot = AR - 1, a_read = 1;           // (wave-uniform) weight slot / A slot the next DMAs go to; A slot read next
+    unsigned b_slot = 1, a_slot = A_SLOTS - 1, a_read = 1;      // (wave-uniform) weight slot / A slot the next DMAs go to; A slot read next
     uint4 fbq[2][3], rawq[2][2];          // weight fragments (block parity, plane); A piece halves (step parity, half)
     unsigned pl[2][3][4];                  // split planes being built (step parity, plane, float pair)
     bf16x8 fa[2][3];
@@ -550,14 +554,17 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
 #define X3H_PACK(SET) do { _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++) \
         fa[SET][p_] = __builtin_bit_cast(bf16x8, make_uint4(pl[SET][p_][0], pl[SET][p_][1], pl[SET][p_][2], pl[SET][p_][3])); } while (0)
     // the six MFMAs of column block J from fa[FS] x fb[CS] (smallest terms first) with the split of pairs PJ J .. of raw[FS ^ 1] behind them
-#define X3H_BLOCK(J, FS, CS) do { \
+    // H1 / H2: statements issued behind the fifth / sixth MFMA (the interleaved schedule's LDS-DMA instructions: their issue -- 16 cycles
+    // of the CU's texture-address path each, more when eight waves queue up -- overlaps the 32 matrix-pipe cycles of the MFMA in front)
+#define X3H_BLOCKH(J, FS, CS, H1, H2) do { \
         const bf16x8 b0_ = __builtin_bit_cast(bf16x8, fbq[CS][0]), b1_ = __builtin_bit_cast(bf16x8, fbq[CS][1]), b2_ = __builtin_bit_cast(bf16x8, fbq[CS][2]); \
         x3h_mfma(acc[J], fa[FS][2], b0_); X3H_PAIR_A((FS) ^ 1, PJ * (J)); \
         x3h_mfma(acc[J], fa[FS][1], b1_); X3H_PAIR_B((FS) ^ 1, PJ * (J)); \
         x3h_mfma(acc[J], fa[FS][0], b2_); if (PJ == 2) X3H_PAIR_A((FS) ^ 1, PJ * (J) + 1); \
         x3h_mfma(acc[J], fa[FS][1], b0_); if (PJ == 2) X3H_PAIR_B((FS) ^ 1, PJ * (J) + 1); \
-        x3h_mfma(acc[J], fa[FS][0], b1_); \
-        x3h_mfma(acc[J], fa[FS][0], b0_); } while (0)
+        x3h_mfma(acc[J], fa[FS][0], b1_); H1; \
+        x3h_mfma(acc[J], fa[FS][0], b0_); H2; } while (0)
+#define X3H_BLOCK(J, FS, CS) X3H_BLOCKH(J, FS, CS, (void)0, (void)0)
     // one 16-k step KS of the current slot using fa[FS]; at its end fa[FS ^ 1] is complete.  _MID: the first block of the slot's next
     // step is prefetched behind the last block; _END: last step of a tile (the next tile's fragments need the barrier first).  LDS
     // operations return in order: with the next block's three reads just issued, lgkmcnt(3) = everything older has landed (the current
@@ -584,12 +591,38 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
             X3H_LGKM(0); X3H_BLOCK(1, FS, 1); \
         } \
         X3H_PACK((FS) ^ 1); } while (0)
+    // the interleaved schedule's steps: step 0 of a tile carries the NQ weight DMAs of tile t + 1 (X3H_DB), step 1 the NA own-row DMAs of
+    // tile t + 2 (X3H_DA), two per column block at most
+#define X3H_DB(I) do { if ((I) < NQ && more_b) x3_asm_dma16((const void*)(b_src[(I) < NQ ? (I) : 0] + (kt + 1) * XBK), b_wave + b_slot * B_BYTES + (I) * 1024u); } while (0)
+#define X3H_DA(I) do { if ((I) < NA && more_a) x3_asm_dma16((const void*)(a_src[(I) < NA ? (I) : 0] + (kt + 2) * XBK), a_wave + a_tgt * A_BYTES + (I) * 1024u); } while (0)
+#define X3H_STEP_MID_IL(KS, FS, NKS) do { \
+        if constexpr (CW == 4) { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCKH(0, FS, 0, X3H_DB(0), X3H_DB(1)); \
+            X3H_FB(KS, 2, 0); X3H_LGKM(3); X3H_BLOCKH(1, FS, 1, X3H_DB(2), X3H_DB(3)); \
+            X3H_FB(KS, 3, 1); X3H_LGKM(3); X3H_BLOCKH(2, FS, 0, X3H_DB(4), X3H_DB(5)); \
+            X3H_FB(NKS, 0, 0); X3H_LGKM(3); X3H_BLOCKH(3 % CW, FS, 1, X3H_DB(6), X3H_DB(7)); \
+        } else { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCKH(0, FS, 0, X3H_DB(0), X3H_DB(1)); \
+            X3H_FB(NKS, 0, 0); X3H_LGKM(3); X3H_BLOCKH(1, FS, 1, X3H_DB(2), X3H_DB(3)); \
+        } \
+        X3H_PACK((FS) ^ 1); } while (0)
+#define X3H_STEP_END_IL(KS, FS) do { \
+        if constexpr (CW == 4) { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCKH(0, FS, 0, X3H_DA(0), (void)0); \
+            X3H_FB(KS, 2, 0); X3H_LGKM(3); X3H_BLOCKH(1, FS, 1, X3H_DA(1), (void)0); \
+            X3H_FB(KS, 3, 1); X3H_LGKM(3); X3H_BLOCKH(2, FS, 0, X3H_DA(2), (void)0); \
+            X3H_LGKM(0); X3H_BLOCKH(3 % CW, FS, 1, X3H_DA(3), (void)0); \
+        } else { \
+            X3H_FB(KS, 1, 1); X3H_LGKM(3); X3H_BLOCKH(0, FS, 0, X3H_DA(0), X3H_DA(1)); \
+            X3H_LGKM(0); X3H_BLOCKH(1, FS, 1, X3H_DA(2), X3H_DA(3)); \
+        } \
+        X3H_PACK((FS) ^ 1); } while (0)
 #define X3H_VM(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
 #define X3H_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
     // prologue: weights and A of tile 0 (and, with the deeper ring, A of tile 1)
     dma_b(0, 0);
     dma_a(0, 0);
-    if (AR == 3 && nk > 1) { dma_a(1, 1); X3H_VM(4); } else X3H_VM(0);
+    if ((AR == 3 || IL) && nk > 1) { dma_a(1, 1); X3H_VM(4); } else X3H_VM(0);
     X3H_BARRIER();
     // fa[0] = step 0 of tile 0 (split here, unhidden, once), raw[1] = step 1's piece -- both from A slot 0
     {
@@ -608,30 +641,32 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
 #define X3D_STAMP(I) do {} while (0)
 #endif
     for (int kt = 0; kt < nk; kt++) {
-        const bool more_b = kt + 1 < nk, more_a = kt + AR - 1 < nk;             // wave-uniform
-        if (AR == 2) { if (more_a) dma_a(kt + 1, a_slot); if (more_b) dma_b(kt + 1, b_slot); }
-        else         { if (more_b) dma_b(kt + 1, b_slot); if (more_a) dma_a(kt + 2, a_slot); }
+        const bool more_b = kt + 1 < nk, more_a = kt + (IL ? 2 : AR - 1) < nk;  // wave-uniform
+        const unsigned a_tgt = a_read ^ 1u;                                      // IL: the slot tile kt's rows came from is free since mid tile kt - 1
+        if (IL) {}
+        else if (AR == 2) { if (more_a) dma_a(kt + 1, a_slot); if (more_b) dma_b(kt + 1, b_slot); }
+        else              { if (more_b) dma_b(kt + 1, b_slot); if (more_a) dma_a(kt + 2, a_slot); }
         X3D_STAMP(0);
         X3H_FB(0, 0, 0);
-        X3H_STEP_MID(0, 0, 1);
+        if constexpr (IL) X3H_STEP_MID_IL(0, 0, 1); else X3H_STEP_MID(0, 0, 1);
         X3D_STAMP(1);
         // this wave's A rows of tile kt + 1 have landed (after the last tile: stale data, split and never used)
-        if (AR == 2) { if (more_b) X3H_VM(NQ); else X3H_VM(0); }
+        if (AR == 2 || IL) { if (more_b) X3H_VM(NQ); else X3H_VM(0); }           // (IL: A(kt + 1) went out a tile ago, only W(kt + 1) is younger)
         else { if (more_b && more_a) X3H_VM(NQ + 4); else if (more_b) X3H_VM(NQ); else X3H_VM(0); }
         X3D_STAMP(2);
         X3H_RAW(0, 0);
         X3H_RAW(1, 1);
-        X3H_STEP_END(1, 1);
+        if constexpr (IL) X3H_STEP_END_IL(1, 1); else X3H_STEP_END(1, 1);
         X3D_STAMP(3);
-        if (AR == 3 && more_a) X3H_VM(4); else X3H_VM(0);       // the weights of tile kt + 1 have landed (A of tile kt + 2 stays in flight)
+        if ((AR == 3 || IL) && more_a) X3H_VM(4); else X3H_VM(0);   // the weights of tile kt + 1 have landed (A of tile kt + 2 stays in flight)
         X3H_BARRIER();                                          // ... everywhere; the current weight slot is free
         X3D_STAMP(4);
         // advance the rings: weights of the slot just filled; A pieces of the slot after the one just read; DMA targets
         {
             const unsigned nb = b_slot;
             b_slot ^= 1u;
-            a_read = a_read + 1 == AR ? 0 : a_read + 1;
-            a_slot = a_slot + 1 == AR ? 0 : a_slot + 1;
+            a_read = a_read + 1 == A_SLOTS ? 0 : a_read + 1;
+            a_slot = a_slot + 1 == A_SLOTS ? 0 : a_slot + 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 vb[ks] = lds_base + A_RING + nb * B_BYTES + f_off[ks];
@@ -924,6 +959,20 @@ int regtr_gemm_x3_preferred(int M, int N, int K)
     return K >= 32 ? 1 : 0;
 }
 
+// Diagnostic: workgroups of the row-strip kernel the runtime will keep resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor)
+// for column width cw (2 | 4 blocks of 32), A-ring mode ar (2 | 3; 4 = interleaved, cw 4 only) and the statistics epilogue; -1 = no such variant.
+int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats)
+{
+    int n = -1;
+    const void* k = nullptr;
+    if (cw == 4 && ar == 2) k = stats ? (const void*)k_gemm_x3d<4, 4, 2, true> : (const void*)k_gemm_x3d<4, 4, 2, false>;
+    else if (cw == 4 && ar == 4) k = stats ? (const void*)k_gemm_x3d<4, 4, 4, true> : (const void*)k_gemm_x3d<4, 4, 4, false>;
+    else if (cw == 2 && ar == 2) k = stats ? (const void*)k_gemm_x3d<4, 2, 2, true> : (const void*)k_gemm_x3d<4, 2, 2, false>;
+    else if (cw == 2 && ar == 3) k = stats ? (const void*)k_gemm_x3d<4, 2, 3, true> : (const void*)k_gemm_x3d<4, 2, 3, false>;
+    if (!k || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, 0) != hipSuccess) return -1;
+    return n;
+}
+
 size_t regtr_gemm_split_weights_bytes(int N, int K)
 {
     const size_t Npad = (size_t)rg_cdiv(N, 128) * 128, Kp = (size_t)rg_cdiv(K, XBK) * XBK;
@@ -1003,7 +1052,14 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     // (measured and left out: 8 waves on 256 x 128 tiles, 144 KiB of LDS, one workgroup per CU -- k_gemm_x3d<8, 4, 3> -- halves the
     // weight traffic per MFMA and is no faster: 498 vs 483 us on the level-2 contraction, 555 vs 478 at level 3 where 296 tiles
     // quantise badly over 256 CUs)
-    if (strip && p.tile == 0) X3D_LAUNCH(4, 4, 2);                   // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
+    static const int il = (getenv("REGTR_X3_IL") && *getenv("REGTR_X3_IL")) ? atoi(getenv("REGTR_X3_IL")) : 1;   // development: A/B runs
+    // Interleaved schedule (A two tiles ahead in TWO slots, every DMA instruction issued between MFMAs) for the 128 x 128 tile: measured
+    // on the 18 RegTR shapes (gpurun_out/r03_z5) sum 4716 -> 4670 us, level-3 contraction 472 -> 458 us; on the 128 x 64 tile it loses
+    // on the strided contractions (153 -> 165, 145 -> 151 us) and is not instantiated.  Hiding the ~1250-cycle DMA-issue phase bought
+    // 1 %, not the 30 % its share of a tile suggested: with two workgroups per CU (regtr_gemm_x3_strip_occupancy) that phase already
+    // overlapped the other workgroup's MFMAs.
+    if (strip && il && p.tile == 0) X3D_LAUNCH(4, 4, 4);
+    else if (strip && p.tile == 0) X3D_LAUNCH(4, 4, 2);              // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
     else if (strip && a_ring == 3) X3D_LAUNCH(4, 2, 3);              // 128 x 64, A rows two tiles ahead
     else if (strip) X3D_LAUNCH(4, 2, 2);                             // 128 x 64
     else if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);     // 128 x 128, 8 waves of 64 x 32
