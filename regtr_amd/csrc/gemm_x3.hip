@@ -556,14 +556,26 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     // the six MFMAs of column block J from fa[FS] x fb[CS] (smallest terms first) with the split of pairs PJ J .. of raw[FS ^ 1] behind them
     // H1 / H2: statements issued behind the fifth / sixth MFMA (the interleaved schedule's LDS-DMA instructions: their issue -- 16 cycles
     // of the CU's texture-address path each, more when eight waves queue up -- overlaps the 32 matrix-pipe cycles of the MFMA in front)
+#ifndef X3H_SPLIT_AFTER
+#define X3H_SPLIT_AFTER 0          // development A-B: 1 = the six MFMAs of a block back to back, the split and DMA instructions after them.
+                                   // Measured (gpurun_out/r03_z7, 18 shapes): 4953 vs 4788 us -- the VALU between same-accumulator MFMAs is
+                                   // not what the matrix pipe waits for here (two waves per SIMD fill each other's gaps); off
+#endif
 #define X3H_BLOCKH(J, FS, CS, H1, H2) do { \
         const bf16x8 b0_ = __builtin_bit_cast(bf16x8, fbq[CS][0]), b1_ = __builtin_bit_cast(bf16x8, fbq[CS][1]), b2_ = __builtin_bit_cast(bf16x8, fbq[CS][2]); \
+        if (X3H_SPLIT_AFTER) { \
+            x3h_mfma(acc[J], fa[FS][2], b0_); x3h_mfma(acc[J], fa[FS][1], b1_); x3h_mfma(acc[J], fa[FS][0], b2_); \
+            x3h_mfma(acc[J], fa[FS][1], b0_); x3h_mfma(acc[J], fa[FS][0], b1_); x3h_mfma(acc[J], fa[FS][0], b0_); \
+            X3H_PAIR_A((FS) ^ 1, PJ * (J)); X3H_PAIR_B((FS) ^ 1, PJ * (J)); \
+            if (PJ == 2) { X3H_PAIR_A((FS) ^ 1, PJ * (J) + 1); X3H_PAIR_B((FS) ^ 1, PJ * (J) + 1); } \
+            H1; H2; \
+        } else { \
         x3h_mfma(acc[J], fa[FS][2], b0_); X3H_PAIR_A((FS) ^ 1, PJ * (J)); \
         x3h_mfma(acc[J], fa[FS][1], b1_); X3H_PAIR_B((FS) ^ 1, PJ * (J)); \
         x3h_mfma(acc[J], fa[FS][0], b2_); if (PJ == 2) X3H_PAIR_A((FS) ^ 1, PJ * (J) + 1); \
         x3h_mfma(acc[J], fa[FS][1], b0_); if (PJ == 2) X3H_PAIR_B((FS) ^ 1, PJ * (J) + 1); \
         x3h_mfma(acc[J], fa[FS][0], b1_); H1; \
-        x3h_mfma(acc[J], fa[FS][0], b0_); H2; } while (0)
+        x3h_mfma(acc[J], fa[FS][0], b0_); H2; } } while (0)
 #define X3H_BLOCK(J, FS, CS) X3H_BLOCKH(J, FS, CS, (void)0, (void)0)
     // one 16-k step KS of the current slot using fa[FS]; at its end fa[FS ^ 1] is complete.  _MID: the first block of the slot's next
     // step is prefetched behind the last block; _END: last step of a tile (the next tile's fragments need the barrier first).  LDS
