@@ -34,8 +34,8 @@ def scan(asm, window):
         ins = [l for l in ins if not l.endswith(':')]
         loads = stalled = 0
         for i, l in enumerate(ins):
-            if not l.startswith(('global_load', 'buffer_load', 'flat_load')) or ' lds' in l:
-                continue
+            if not l.startswith(('global_load', 'buffer_load', 'flat_load')) or ' lds' in l or '_lds_' in l.split()[0]:
+                continue        # (LDS-DMA loads are waited for by count, by design)
             loads += 1
             for nxt in ins[i + 1:i + 1 + window]:
                 if nxt.startswith(('global_load', 'buffer_load', 'flat_load')):
@@ -59,7 +59,7 @@ def structure(asm, needle):
             if l.endswith(':') and l.startswith('.LBB'):
                 ev.append('|')
             elif l.startswith(('global_load', 'buffer_load', 'flat_load')):
-                ev.append('D' if ' lds' in l else 'L')
+                ev.append('D' if (' lds' in l or '_lds_' in l.split()[0]) else 'L')
             elif l.startswith('s_waitcnt') and 'vmcnt(' in l:
                 ev.append('W' + l.split('vmcnt(')[1].split(')')[0])
             elif l.startswith(('global_store', 'buffer_store')):
