@@ -53,7 +53,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 5
+#define REGTR_ABI_VERSION 6
 int regtr_abi_version(void);
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
@@ -203,6 +203,13 @@ int regtr_gemm_x3_supported(int M, int N, int K);
 int regtr_gemm_x3_preferred(int M, int N, int K);   /* supported AND measured faster than regtr_gemm_f32 (K >= 32) */
 size_t regtr_gemm_split_weights_bytes(int N, int K);
 int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
+/* The f16 pair operand format (n_planes = 4 of regtr_gemm_x3): x = h0 + h1 / 2048, h0 = f16(x), h1 = f16((x - h0) * 2048) -- 22 mantissa
+ * bits in two planes; a product is three v_mfma_f32_32x32x16_f16 (the two low terms in a second, scaled accumulator) at float32-grade
+ * accuracy (error vs float64 within 3x of the six-term bf16 split's on RegTR's shapes), half the matrix-pipe work of the bf16 split.
+ * Operands must stay below 65504 in magnitude.  Served by the row-strip kernel only: regtr_gemm_x3_f16_supported(M, N, K). */
+int regtr_gemm_x3_f16_supported(int M, int N, int K);
+size_t regtr_gemm_split_weights_f16_bytes(int N, int K);
+int regtr_gemm_split_weights_f16(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
 /* diagnostic: resident workgroups per CU of the row-strip split kernel (cw 2|4 column blocks, ar 2|3|4 A-ring mode, stats epilogue) */
 int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats);

@@ -71,6 +71,27 @@ __device__ __forceinline__ void x3_split2(float a, float b, unsigned& p0, unsign
     p2 = x3_pack(ra - __uint_as_float(p1 << 16), rb - __uint_as_float(p1 & 0xffff0000u));
 }
 
+// ---- f16 pair split (operand format 1, "f16x2s"): x = h0 + h1 / 2048 with h0 = f16(x), h1 = f16((x - h0) * 2048) -- 22 mantissa bits in
+// TWO planes where the bf16 split needs three for 24.  A product is a0 w0 + (a0 w1 + a1 w0) / 2048 + O(2^-22 |a w|): THREE
+// v_mfma_f32_32x32x16_f16 instead of six bf16 ones, the two low terms in a second accumulator that is scaled once in the epilogue
+// (the scale keeps the low planes out of f16's subnormal range, where an unscaled residual of anything below 0.12 would sit).
+// Range: |x| < 65504 (f16); values below 6.1e-5 have a subnormal (coarse) h0 whose rounding the scaled h1 picks up again.
+typedef _Float16 x3_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 x3_f16x2 __attribute__((ext_vector_type(2)));
+constexpr float X3_F16_SCALE = 2048.f;
+__device__ __forceinline__ unsigned x3_pack_f16(float a, float b)
+{
+    x3_f16x2 v;
+    v.x = (_Float16)a; v.y = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void x3_split2_f16(float a, float b, unsigned& p0, unsigned& p1)
+{
+    p0 = x3_pack_f16(a, b);
+    const x3_f16x2 h = __builtin_bit_cast(x3_f16x2, p0);
+    p1 = x3_pack_f16((a - (float)h.x) * X3_F16_SCALE, (b - (float)h.y) * X3_F16_SCALE);
+}
+
 // NP = bf16 planes per operand: 3 = float32-grade (six MFMA terms, the default); 2 = the three leading terms a0 w0 + a0 w1 +
 // a1 w0 (relative error ~2^-16 per product); 1 = plain bf16 operands (cfg.compute_dtype 'bf16').
 template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT, int NP = 3>      // MW x NW waves, wave tile (32 WM) x (32 WN)
@@ -429,6 +450,30 @@ __device__ __forceinline__ void x3h_split_b(float ra, float rb, unsigned& p1, un
                  : "=&v"(p1), "=&v"(p2), "=&v"(t0), "=&v"(t1), "=&v"(sa), "=&v"(sb) : "v"(ra), "v"(rb));
 }
 #define X3H_LGKM(N) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory")
+// ---- the same for the f16 pair format (three MFMA terms; x = h0 + h1 / 2048)
+__device__ __forceinline__ void x3h_mfma_f16(floatx16& c, const bf16x8& a, const bf16x8& b)      // (operands are eight f16; the type only carries the bits)
+{
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// first half of the split of a float pair: p0 = f16 pair, (ha, hb) = its two values back in float32
+__device__ __forceinline__ void x3h_splitf_a(float a, float b, unsigned& p0, float& ha, float& hb)
+{
+    asm volatile("v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+                 "v_cvt_f32_f16_e32 %1, %0\n\t"
+                 "v_cvt_f32_f16_sdwa %2, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+                 : "=&v"(p0), "=&v"(ha), "=&v"(hb) : "v"(a), "v"(b));
+}
+// second half: p1 = f16 pair of the residuals scaled by 2048 (0x45000000)
+__device__ __forceinline__ void x3h_splitf_b(float a, float b, float ha, float hb, unsigned& p1)
+{
+    float t0, t1;
+    asm volatile("v_sub_f32 %1, %3, %5\n\t"
+                 "v_sub_f32 %2, %4, %6\n\t"
+                 "v_mul_f32 %1, 0x45000000, %1\n\t"
+                 "v_mul_f32 %2, 0x45000000, %2\n\t"
+                 "v_cvt_pk_f16_f32 %0, %1, %2"
+                 : "=&v"(p1), "=&v"(t0), "=&v"(t1) : "v"(a), "v"(b), "v"(ha), "v"(hb));
+}
 #ifndef X3D_HAND
 #define X3D_HAND 1       // development (REGTR_VARIANT_FLAGS=-DX3D_HAND=0): the compiler-scheduled k loop for A/B runs
 #endif
@@ -436,9 +481,11 @@ __device__ __forceinline__ void x3h_split_b(float ra, float rb, unsigned& p1, un
 // MW waves (4 or 8: 128- or 256-row tiles; the weight tile is shared by all of them, so twice the rows halve the weight traffic per
 // MFMA), CW 32-column blocks per wave, AR slots of the wave-private A ring (3: the A rows of tile t + 2 are in flight while tile t is
 // multiplied -- a full tile more than the weights get, which hit L2 while A comes from HBM), NP planes.
-template <int MW, int CW, int AR, bool SOUT, int NP = 3>
+// FMT: operand format -- 0 = NP bf16 planes, 1 = the f16 pair (NP = 2 planes, three MFMA terms, second accumulator for the low terms)
+template <int MW, int CW, int AR, bool SOUT, int NP = 3, int FMT = 0>
 __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
 {
+    static_assert(FMT == 0 || (FMT == 1 && NP == 2 && AR == 2), "the f16 pair format has two planes and runs the compiler-scheduled loop");
     constexpr int NT = 64 * MW, BM = 32 * MW, BN = 32 * CW;
     constexpr int A_BYTES = BM * XBK * 4;                      // raw float32 rows of one k-tile: 128 bytes per row
     constexpr int B_BYTES = NP * BN * XROW;
@@ -446,7 +493,9 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     // AR = 4: the INTERLEAVED schedule -- two A slots, A two tiles ahead, every LDS-DMA instruction issued between MFMAs (see the hand loop)
     constexpr bool IL = AR == 4;
     constexpr int A_SLOTS = AR == 3 ? 3 : 2;
-    constexpr int A_RING = A_SLOTS * A_BYTES, LDS_BYTES = A_RING + 2 * B_BYTES;
+    constexpr int A_RING = A_SLOTS * A_BYTES, RING_BYTES = A_RING + 2 * B_BYTES;
+    constexpr int STAT_BYTES = SOUT ? BM * BN * 4 + (NT / BN) * BN * 16 : 0;      // the statistics epilogue's tile image + partial sums
+    constexpr int LDS_BYTES = RING_BYTES > STAT_BYTES ? RING_BYTES : STAT_BYTES;
     static_assert(NQ * 1024 * MW == B_BYTES && NQ >= 1, "the weight tile must split evenly over the waves");
     static_assert(AR == 2 || AR == 3 || AR == 4, "A ring mode");
     static_assert(!IL || (NP == 3 && X3D_HAND), "the interleaved schedule exists in the hand-scheduled loop only");
@@ -516,10 +565,11 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
         }
     }
     floatx16 acc[CW];
+    floatx16 acc_lo[FMT == 1 ? CW : 1];                         // f16 pair: the two scaled low terms
 #pragma unroll
     for (int j = 0; j < CW; j++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+        for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; if (FMT == 1) acc_lo[FMT == 1 ? j : 0][r] = 0.f; }
 
     if constexpr (NP == 3 && X3D_HAND) {
     // ---- hand-scheduled k loop.  Per 16-k step and column block: three fragment reads of the NEXT block are issued, the wait
@@ -693,6 +743,86 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
         printf("x3d M %d N %d K %d MW %d CW %d AR %d blk %d wave %d nk %d: dma-issue %lld step0 %lld own-A-wait %lld step1 %lld sync %lld (cycles)\n", g.M, g.N, g.K,
                MW, CW, AR, (int)blockIdx.x, wave, nk, pt[0], pt[1], pt[2], pt[3], pt[4]);
 #endif
+    } else if constexpr (FMT == 1 && X3D_HAND) {
+    // ---- hand-scheduled k loop of the f16 pair format, 128 x 64 tiles.  The interleaved schedule of the bf16 loop above (two A slots, own
+    // rows two tiles ahead, every LDS-DMA instruction issued between MFMAs), with TWO planes per operand and THREE MFMAs per column
+    // block -- a0 w1 into the low accumulator, a0 w0 into the high one, a1 w0 into the low one -- and the f16 split of the next step's A
+    // piece (cvt_pk / two cvt back / two sub / two mul / cvt_pk per float pair) behind them.
+    static_assert(CW == 2 && NQ <= 2, "the f16 pair hand loop is written for 128 x 64 tiles");
+    unsigned vb[2], va[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        vb[ks] = lds_base + A_RING + f_off[ks];
+        va[ks][0] = lds_base + A_BYTES + fa_off[ks][0];
+        va[ks][1] = lds_base + A_BYTES + fa_off[ks][1];
+    }
+    unsigned b_slot = 1, a_read = 1;           // (wave-uniform) weight slot the next DMAs go to; A slot read next (tile kt + 1's rows)
+    uint4 fbq[2][2], rawq[2][2];               // weight fragments (block parity, plane); A piece halves (step parity, half)
+    unsigned pl[2][2][4];                       // split planes being built (step parity, plane, float pair)
+    bf16x8 fa[2][2];
+    float ha = 0.f, hb = 0.f;
+#define X3F_FB(KS, J, SET) do { x3h_lds128<(0 * BN + (J) * 32) * XROW>(fbq[SET][0], vb[KS]); \
+                                x3h_lds128<(1 * BN + (J) * 32) * XROW>(fbq[SET][1], vb[KS]); } while (0)
+#define X3F_RAW(KS, SET) do { x3h_lds128<0>(rawq[SET][0], va[KS][0]); x3h_lds128<0>(rawq[SET][1], va[KS][1]); } while (0)
+#define X3F_PAIR_A(SET, Q) do { const uint4 v_ = rawq[SET][(Q) >> 1]; \
+        x3h_splitf_a(__uint_as_float(((Q) & 1) ? v_.z : v_.x), __uint_as_float(((Q) & 1) ? v_.w : v_.y), pl[SET][0][Q], ha, hb); } while (0)
+#define X3F_PAIR_B(SET, Q) do { const uint4 v_ = rawq[SET][(Q) >> 1]; \
+        x3h_splitf_b(__uint_as_float(((Q) & 1) ? v_.z : v_.x), __uint_as_float(((Q) & 1) ? v_.w : v_.y), ha, hb, pl[SET][1][Q]); } while (0)
+#define X3F_PACK(SET) do { _Pragma("unroll") for (int p_ = 0; p_ < 2; p_++) \
+        fa[SET][p_] = __builtin_bit_cast(bf16x8, make_uint4(pl[SET][p_][0], pl[SET][p_][1], pl[SET][p_][2], pl[SET][p_][3])); } while (0)
+#define X3F_BLOCK(J, FS, CS, H1, H2) do { \
+        const bf16x8 b0_ = __builtin_bit_cast(bf16x8, fbq[CS][0]), b1_ = __builtin_bit_cast(bf16x8, fbq[CS][1]); \
+        x3h_mfma_f16(acc_lo[J], fa[FS][1], b0_); X3F_PAIR_A((FS) ^ 1, 2 * (J)); \
+        x3h_mfma_f16(acc[J], fa[FS][0], b0_); X3F_PAIR_B((FS) ^ 1, 2 * (J)); H1; \
+        x3h_mfma_f16(acc_lo[J], fa[FS][0], b1_); X3F_PAIR_A((FS) ^ 1, 2 * (J) + 1); X3F_PAIR_B((FS) ^ 1, 2 * (J) + 1); H2; } while (0)
+#define X3F_DB(I) do { if ((I) < NQ && more_b) x3_asm_dma16((const void*)(b_src[(I) < NQ ? (I) : 0] + (kt + 1) * XBK), b_wave + b_slot * B_BYTES + (I) * 1024u); } while (0)
+#define X3F_DA(I) do { if (more_a) x3_asm_dma16((const void*)(a_src[I] + (kt + 2) * XBK), a_wave + a_tgt * A_BYTES + (I) * 1024u); } while (0)
+#define X3F_VM(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
+#define X3F_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // prologue: weights and own rows of tile 0, own rows of tile 1
+    dma_b(0, 0);
+    dma_a(0, 0);
+    if (nk > 1) { dma_a(1, 1); X3F_VM(4); } else X3F_VM(0);
+    X3F_BARRIER();
+    {
+        unsigned a00 = lds_base + fa_off[0][0], a01 = lds_base + fa_off[0][1], a10 = lds_base + fa_off[1][0], a11 = lds_base + fa_off[1][1];
+        x3h_lds128<0>(rawq[0][0], a00); x3h_lds128<0>(rawq[0][1], a01);
+        x3h_lds128<0>(rawq[1][0], a10); x3h_lds128<0>(rawq[1][1], a11);
+    }
+    X3H_LGKM(0);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { X3F_PAIR_A(0, q); X3F_PAIR_B(0, q); }
+    X3F_PACK(0);
+    for (int kt = 0; kt < nk; kt++) {
+        const bool more_b = kt + 1 < nk, more_a = kt + 2 < nk;     // wave-uniform
+        const unsigned a_tgt = a_read ^ 1u;                         // tile kt's own rows were read (raw) half a tile ago: their slot takes tile kt + 2
+        X3F_FB(0, 0, 0);
+        // step 0 (fa[0]); behind it: the split of this tile's second A piece (raw[1] -> fa[1]) and the weight DMAs of tile kt + 1
+        X3F_FB(0, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 0, 0, X3F_DB(0), X3F_DB(1));
+        X3F_FB(1, 0, 0); X3H_LGKM(2); X3F_BLOCK(1, 0, 1, (void)0, (void)0);
+        X3F_PACK(1);
+        if (more_b) X3F_VM(NQ); else X3F_VM(0);                     // this wave's rows of tile kt + 1 have landed (issued a tile ago; only W(kt + 1) is younger)
+        X3F_RAW(0, 0);
+        X3F_RAW(1, 1);
+        // step 1 (fa[1]); behind it: the split of the next tile's first A piece (raw[0] -> fa[0]) and the own-row DMAs of tile kt + 2
+        X3F_FB(1, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 1, 0, X3F_DA(0), X3F_DA(1));
+        X3H_LGKM(0); X3F_BLOCK(1, 1, 1, X3F_DA(2), X3F_DA(3));
+        X3F_PACK(0);
+        if (more_a) X3F_VM(4); else X3F_VM(0);                      // W(kt + 1) has landed (the rows of tile kt + 2 stay in flight)
+        X3F_BARRIER();
+        {
+            const unsigned nb = b_slot;
+            b_slot ^= 1u;
+            a_read ^= 1u;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                vb[ks] = lds_base + A_RING + nb * B_BYTES + f_off[ks];
+                va[ks][0] = lds_base + a_read * A_BYTES + fa_off[ks][0];
+                va[ks][1] = lds_base + a_read * A_BYTES + fa_off[ks][1];
+            }
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // MFMA results -> the epilogue's reads (the compiler does not see the MFMAs)
     } else {
     // ---- compiler-scheduled k loop (one / two planes per operand: cfg.compute_dtype 'bf16' / 'bf16x2'; development builds -DX3D_HAND=0)
     static_assert(AR == 2, "the compiler-scheduled loop uses the two-slot A ring");
@@ -707,8 +837,13 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     };
     auto split_pair = [&](int set, int q) {                   // float pair q (0..3) of raw[set] -> pl[.][q]
         const float4 v = raw[set][q >> 1];
-        if (q & 1) x3_split2(v.z, v.w, pl[0][q], pl[1][q], pl[2][q]);
-        else x3_split2(v.x, v.y, pl[0][q], pl[1][q], pl[2][q]);
+        if (FMT == 1) {
+            if (q & 1) x3_split2_f16(v.z, v.w, pl[0][q], pl[1][q]);
+            else x3_split2_f16(v.x, v.y, pl[0][q], pl[1][q]);
+        } else {
+            if (q & 1) x3_split2(v.z, v.w, pl[0][q], pl[1][q], pl[2][q]);
+            else x3_split2(v.x, v.y, pl[0][q], pl[1][q], pl[2][q]);
+        }
     };
     auto pack_fa = [&](int set) {
 #pragma unroll
@@ -726,10 +861,17 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
             if (jj + 1 < CW) read_fb(Bb, ks, jj + 1, cs ^ 1);
             else if (have_next) read_fb(Bn, ksn, 0, cs ^ 1);
 #define X3D_TERM(PA, PB) acc[jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[fs][PA], fb[cs][PB], acc[jj], 0, 0, 0);
+#define X3D_TERM_F16(ACC, PA, PB) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, fa[fs][PA]), \
+                                                                                __builtin_bit_cast(x3_f16x8, fb[cs][PB]), ACC, 0, 0, 0);
+            if constexpr (FMT == 1) {
+                X3D_TERM_F16(acc_lo[jj], 1, 0) X3D_TERM_F16(acc[jj], 0, 0) X3D_TERM_F16(acc_lo[jj], 0, 1)      // (alternating accumulators)
+            } else {
             if (NP == 3) { X3D_TERM(2, 0) X3D_TERM(1, 1) X3D_TERM(0, 2) }
             if (NP >= 2) { X3D_TERM((NP >= 2 ? 1 : 0), 0) X3D_TERM(0, (NP >= 2 ? 1 : 0)) }
             X3D_TERM(0, 0)
+            }
 #undef X3D_TERM
+#undef X3D_TERM_F16
 #pragma unroll
             for (int q = 0; q < PJ; q++) split_pair(fs ^ 1, jj * PJ + q);
         }
@@ -777,6 +919,12 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     // consecutive floats -- conflict free), from which the per-cloud column sums are taken once the accumulators are dead: doing the
     // float64 sums on the live accumulators put every statistics variant at the 256-register cliff (the CW = 2 one spilled around the
     // asm loop and broke it).
+    if constexpr (FMT == 1) {                              // f16 pair: fold the scaled low terms in
+#pragma unroll
+        for (int j = 0; j < CW; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[j][r] += acc_lo[j][r] * (1.0f / X3_F16_SCALE);
+    }
     float* T = (float*)&sm[0];                             // [BM][BN], free after the k loop's last barrier
 #pragma unroll
     for (int j = 0; j < CW; j++) {
@@ -873,6 +1021,21 @@ __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__
     x3_split2(w, 0.f, p0, p1, p2);
     const size_t plane = (size_t)Npad * Kp;
     Wt[e] = (uint16_t)(p0 & 0xffffu); Wt[plane + e] = (uint16_t)(p1 & 0xffffu); Wt[2 * plane + e] = (uint16_t)(p2 & 0xffffu);
+}
+
+// the same for the f16 pair format: Wt[2][Npad][Kp] f16 (plane 1 = scaled residual)
+__global__ void __launch_bounds__(256) k_split_weights_f16(const float* __restrict__ W, int ld, int N, int K, int transposed,
+                                                           int Npad, int Kp, uint16_t* __restrict__ Wt)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)Npad * Kp) return;
+    const int n = (int)(e / Kp), k = (int)(e % Kp);
+    float w = 0.f;
+    if (n < N && k < K) w = transposed ? W[(size_t)k * ld + n] : W[(size_t)n * ld + k];
+    unsigned p0, p1;
+    x3_split2_f16(w, 0.f, p0, p1);
+    const size_t plane = (size_t)Npad * Kp;
+    Wt[e] = (uint16_t)(p0 & 0xffffu); Wt[plane + e] = (uint16_t)(p1 & 0xffffu);
 }
 
 // tile t of `rows` rows -> (first cloud, last cloud, first cloud's begin, first cloud's end); one thread per tile
@@ -1003,6 +1166,31 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
     return RG_OK;
 }
 
+// f16 pair format (regtr_gemm_x3 with n_planes = 4): served by the row-strip kernel only -- N a multiple of 64, K a multiple of 32, and
+// a tile plan that takes the strip form (tall problems); no folded A operand
+int regtr_gemm_x3_f16_supported(int M, int N, int K)
+{
+    if (!regtr_gemm_x3_supported(M, N, K) || N < 64 || K % XBK) return 0;
+    const X3Plan p = x3_plan(M, N, K);
+    return (p.strip && p.k_chunk % XBK == 0) ? 1 : 0;
+}
+
+size_t regtr_gemm_split_weights_f16_bytes(int N, int K)
+{
+    const size_t Npad = (size_t)rg_cdiv(N, 128) * 128, Kp = (size_t)rg_cdiv(K, XBK) * XBK;
+    return 2 * Npad * Kp * sizeof(uint16_t);
+}
+
+int regtr_gemm_split_weights_f16(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream)
+{
+    if (!W || !planes || N < 1 || K < 1 || ld < (transposed ? N : K)) return RG_ERR_ARG;
+    const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
+    k_split_weights_f16<<<rg_cdiv((long long)Npad * Kp, 256), 256, 0, (hipStream_t)stream>>>(W, ld, N, K, transposed, Npad, Kp,
+                                                                                             (uint16_t*)planes);
+    RG_RETURN_IF_LAUNCH_FAILED();
+    return RG_OK;
+}
+
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K)
 {
     if (!regtr_gemm_x3_supported(M, N, K)) return 0;
@@ -1032,12 +1220,16 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
 {
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
     if (tile_info && a_stats && stat_partial && (a_seg_off != stat_seg_off || n_seg != n_stat_seg)) return RG_ERR_ARG;
-    if (n_planes < 1 || n_planes > 3 || (n_planes != 3 && (a_stats || stat_partial))) return RG_ERR_ARG;
+    // n_planes: 1 | 2 | 3 bf16 planes (regtr_gemm_split_weights); 4 = the f16 pair of regtr_gemm_split_weights_f16 (three MFMA terms at
+    // float32-grade accuracy; row-strip kernel only: regtr_gemm_x3_f16_supported)
+    if (n_planes < 1 || n_planes > 4 || ((n_planes == 1 || n_planes == 2) && (a_stats || stat_partial)) || (n_planes == 4 && a_stats)) return RG_ERR_ARG;
+    if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K)) return RG_ERR_ARG;
     if (N == 32 && a_stats) return RG_ERR_ARG;               // the thin case exists on the row-strip kernel only
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
-    const X3Plan p = x3_plan(M, N, K);
+    X3Plan p = x3_plan(M, N, K);
+    if (n_planes == 4 && p.tile == 0) p.tile = 1;           // the f16 pair's two accumulator sets fit the register file at 128 x 64 only (128 x 128: 256 VGPRs + spills)
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
     if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
@@ -1055,7 +1247,9 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
         else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)
 #define X3D_LAUNCH(MW_, CW_, AR_) do { \
-        if (n_planes == 1) k_gemm_x3d<4, CW_, 2, false, 1><<<grid, 256, 0, st>>>(g); \
+        if (n_planes == 4) { if (stat_partial) k_gemm_x3d<4, 2, 2, true, 2, 1><<<grid, 256, 0, st>>>(g); \
+                             else k_gemm_x3d<4, 2, 2, false, 2, 1><<<grid, 256, 0, st>>>(g); } \
+        else if (n_planes == 1) k_gemm_x3d<4, CW_, 2, false, 1><<<grid, 256, 0, st>>>(g); \
         else if (n_planes == 2) k_gemm_x3d<4, CW_, 2, false, 2><<<grid, 256, 0, st>>>(g); \
         else if (stat_partial) k_gemm_x3d<MW_, CW_, AR_, true><<<grid, 64 * MW_, 0, st>>>(g); \
         else k_gemm_x3d<MW_, CW_, AR_, false><<<grid, 64 * MW_, 0, st>>>(g); } while (0)

@@ -118,10 +118,52 @@ class SplitWeight:
             self.K, self.N = w.shape
             self.kn = w
         self.planes = None
+        self._w, self._layout, self._planes16 = w, layout, None
         if L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
             check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
                                              stream()), 'regtr_gemm_split_weights')
+
+
+    @property
+    def planes16(self):
+        """The f16 pair planes of regtr_gemm_split_weights_f16 (regtr_gemm_x3's n_planes = 4), built on first use."""
+        if self._planes16 is None:
+            L = _lib.lib()
+            self._planes16 = _ws(L.regtr_gemm_split_weights_f16_bytes(self.N, self.K), self._w.device)
+            check(L.regtr_gemm_split_weights_f16(ptr(self._w), self._w.stride(0), self.N, self.K, 0 if self._layout == 'nk' else 1,
+                                                 bptr(self._planes16), stream()), 'regtr_gemm_split_weights_f16')
+        return self._planes16
+
+
+# float32-grade contractions as three f16 MFMA terms (the f16 pair split, csrc/gemm_x3.hip) where the row-strip kernel serves the shape,
+# instead of six (planes = 3) / three (planes = 2) bf16 terms.  f16_pair_default: what cfg.compute_dtype 'fp32' asks for (A-B runs:
+# REGTR_F16_PAIR=0); use_f16_pair: the switch gemm() reads, set per forward by RegTR (`with ops.f16_pair(flag)`) and by tests.
+f16_pair_default = os.environ.get('REGTR_F16_PAIR', '1') != '0'
+use_f16_pair = False
+_f16_shape = {}
+
+
+class f16_pair:
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global use_f16_pair
+        self.prev, use_f16_pair = use_f16_pair, self.on
+
+    def __exit__(self, *exc):
+        global use_f16_pair
+        use_f16_pair = self.prev
+
+
+def f16_pair_ok(M, N, K):
+    v = _f16_shape.get((M, N, K))
+    if v is None:
+        if len(_f16_shape) > 4096:
+            _f16_shape.clear()
+        v = _f16_shape[(M, N, K)] = bool(_lib.lib().regtr_gemm_x3_f16_supported(M, N, K))
+    return v
 
 
 _x3_shape = {}       # (M, N, K) -> (supported, preferred, workspace bytes, statistics tile rows, launch tile rows): host-side plan queries, memoised
@@ -179,10 +221,13 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         ti = None
         if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
             ti = tile_segments(seg_rows, M, x3_rows)
-        check(L.regtr_gemm_x3(raw(a), lda, bptr(sw.planes), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
+        pl, npl = sw.planes, int(planes)
+        if use_f16_pair and npl >= 2 and a_stats is None and f16_pair_ok(M, N, K):
+            pl, npl = sw.planes16, 4
+        check(L.regtr_gemm_x3(raw(a), lda, bptr(pl), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
-                              int(planes), iptr(ti), stream()), 'regtr_gemm_x3')
+                              npl, iptr(ti), stream()), 'regtr_gemm_x3')
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
             check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),

@@ -119,18 +119,22 @@ class RegTR(nn.Module):
             normalize_before=cfg.pre_norm, sa_val_has_pos_emb=cfg.sa_val_has_pos_emb,
             ca_val_has_pos_emb=cfg.ca_val_has_pos_emb, attention_type=cfg.attention_type)
         encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
-        # cfg.compute_dtype (not a reference key).  'fp32' (default): every contraction on the bf16 matrix cores with exact operand
-        # splits -- six MFMA terms (float32-grade, error ~2^-24 per product) in the KPConv encoder, feat_proj, attention core, head and
-        # pose; the CROSS-ENCODER's Linears (in / out projections, FFN) keep the three leading terms (2^-16 per product before
-        # accumulation): validated against the real reference module's outputs on all five goldens in parity mode (worst 3.3e-5 vs
-        # 2.4e-5 with six terms, bar 1e-4; profiles/r03_dtype_parity.txt), 3 % faster end to end.  'fp32x3' = six terms everywhere;
-        # 'bf16x2' = alias of the default's cross-encoder setting (kept for round-2 callers); 'bf16' = plain bf16 operands with float32
-        # accumulation / softmax in the cross-encoder's linears and attention core (BASELINE configs[1]; encoder, head, pose as 'fp32').
+        # cfg.compute_dtype (not a reference key).  Every contraction runs on the 16-bit matrix cores with EXACT operand splits and
+        # float32 accumulation.  'fp32' (default): where the row-strip GEMM serves the shape (the tall problems of a batched forward), the
+        # f16 PAIR split -- x = h0 + h1 / 2048, three f16 MFMA terms, error ~2^-22 per product, operands must stay below f16's 65504
+        # (InstanceNorm / LayerNorm outputs and their gathered sums are; a larger value gives a non-finite output, loudly) -- and
+        # elsewhere the bf16 splits: six terms (~2^-24) in the KPConv encoder, feat_proj, attention core, head and pose, the three
+        # leading terms (2^-16) in the cross-encoder's Linears.  Validated against the real reference module's outputs on all five
+        # goldens in parity mode (worst 3.3e-5, bar 1e-4; profiles/r03_dtype_parity.txt) and on the benchmarked batch (bench.py's
+        # `parity`).  'fp32x3' = six bf16 terms everywhere (full float32 operand range, no f16); 'bf16x2' = the bf16 three-term
+        # cross-encoder without the f16 pair (round-2 callers); 'bf16' = plain bf16 operands with float32 accumulation / softmax in the
+        # cross-encoder's Linears and attention core (BASELINE configs[1]; encoder, head, pose as 'fp32').
         dt = cfg.get('compute_dtype', 'fp32')
         if dt not in ('fp32', 'fp32x3', 'bf16', 'bf16x2'):
             raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, fp32x3, bf16x2 or bf16')
         encoder_layer.gemm_planes = {'fp32': 2, 'fp32x3': 3, 'bf16x2': 2, 'bf16': 1}[dt]
         encoder_layer.attn_precision = 1 if dt == 'bf16' else 0
+        self._f16_pair = dt in ('fp32', 'bf16') and ops.f16_pair_default      # ('bf16': the encoder / head GEMMs, which stay float32-grade)
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)
         if cfg.get('direct_regress_coor', False):                                 # :68-73
@@ -181,7 +185,7 @@ class RegTR(nn.Module):
         if any(p.device != dev for p in clouds) or self._model_device != dev:
             raise RuntimeError(f'RegTR.forward: the model ({self._model_device}) and every input cloud must live on one GPU ({dev})')
         # kernels go to torch's current stream of the CURRENT device: make the tensors' device current for the whole forward
-        with _lib.on_device(dev):
+        with _lib.on_device(dev), ops.f16_pair(self._f16_pair):
             return self._forward(batch, dev)
 
     def _forward(self, batch, dev):

@@ -142,7 +142,13 @@ class TransformerCrossEncoder(nn.Module):
                 return False
         return bool(_lib.lib().regtr_cross_encoder_supported(x.shape[0], x.shape[1], l0.linear1.out_features, l0.nhead))
 
-    def _param_table(self):
+    def _f16_pair(self, n):
+        l0 = self.layers[0]
+        D, F = l0.d_model, l0.linear1.out_features
+        return bool(ops.use_f16_pair and l0.gemm_planes >= 2 and ops.f16_pair_ok(n, 3 * D, D) and ops.f16_pair_ok(n, D, D)
+                    and ops.f16_pair_ok(n, F, D) and ops.f16_pair_ok(n, D, F))
+
+    def _param_table(self, f16=False):
         """(ctypes array of the layers' device pointers in regtr_cross_encoder_fwd's order, ctypes array of the norm eps) -- rebuilt only
         when a pointer changes; the tensors behind the pointers are kept alive by the modules / the layers' weight caches."""
         ptrs, eps = [], []
@@ -151,11 +157,12 @@ class TransformerCrossEncoder(nn.Module):
             sa, ca = m['self_attn'], m['multihead_attn']
             n1, n2, n3, l1, l2 = m['norm1'], m['norm2'], m['norm3'], m['linear1'], m['linear2']
             eps += [n1.eps, n2.eps, n3.eps]
-            for t in (n1.weight, n1.bias, layer._wt('sa_in', sa.in_proj_weight).planes, sa.in_proj_bias,
-                      layer._wt('sa_out', sa.out_proj.weight).planes, sa.out_proj.bias,
-                      n2.weight, n2.bias, layer._wt('ca_in', ca.in_proj_weight).planes, ca.in_proj_bias,
-                      layer._wt('ca_out', ca.out_proj.weight).planes, ca.out_proj.bias,
-                      n3.weight, n3.bias, layer._wt('l1', l1.weight).planes, l1.bias, layer._wt('l2', l2.weight).planes, l2.bias):
+            pl = (lambda sw: sw.planes16) if f16 else (lambda sw: sw.planes)
+            for t in (n1.weight, n1.bias, pl(layer._wt('sa_in', sa.in_proj_weight)), sa.in_proj_bias,
+                      pl(layer._wt('sa_out', sa.out_proj.weight)), sa.out_proj.bias,
+                      n2.weight, n2.bias, pl(layer._wt('ca_in', ca.in_proj_weight)), ca.in_proj_bias,
+                      pl(layer._wt('ca_out', ca.out_proj.weight)), ca.out_proj.bias,
+                      n3.weight, n3.bias, pl(layer._wt('l1', l1.weight)), l1.bias, pl(layer._wt('l2', l2.weight)), l2.bias):
                 ptrs.append(t.data_ptr())
         key = (tuple(ptrs), tuple(eps))
         if self._table is None or self._table[0] != key:
@@ -170,7 +177,8 @@ class TransformerCrossEncoder(nn.Module):
         l0 = self.layers[0]
         n, D = x.shape
         F = l0.linear1.out_features
-        table, eps = self._param_table()
+        f16 = self._f16_pair(n)
+        table, eps = self._param_table(f16)
         nb = L.regtr_cross_encoder_ws_bytes(n, D, F)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         g = b = None
@@ -179,7 +187,7 @@ class TransformerCrossEncoder(nn.Module):
             g, b, feps = self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps
         _lib.check(L.regtr_cross_encoder_fwd(_lib.ptr(x), n, D, F, l0.nhead, self.num_layers, table, eps, _lib.ptr(g), _lib.ptr(b), feps,
                                              1 if self.return_intermediate else 0, _lib.ptr(pe), _lib.iptr(seg_off), _lib.iptr(kv_self),
-                                             _lib.iptr(kv_cross), seg_off.numel() - 1, int(max_len), int(l0.gemm_planes),
+                                             _lib.iptr(kv_cross), seg_off.numel() - 1, int(max_len), 4 if f16 else int(l0.gemm_planes),
                                              int(l0.attn_precision), _lib.bptr(ws), nb, _lib.ptr(outs), _lib.stream()),
                    'regtr_cross_encoder_fwd')
         return outs

@@ -684,6 +684,41 @@ def test_gemm_x3_plane_count(planes, tol, x3_forced):
     assert err < tol
 
 
+@pytest.mark.parametrize('M,N,K,scale', [(150000, 128, 256, 1.0), (70000, 64, 960, 1.0), (66000, 256, 512, 1e-4), (66000, 128, 1920, 20.0)])
+def test_gemm_f16_pair_vs_fp64(M, N, K, scale):
+    """The f16 pair operand format (regtr_gemm_x3 n_planes = 4: x = h0 + h1 / 2048, three f16 MFMA terms, scaled second accumulator) vs
+    float64, next to the six-term bf16 split on the same operands: float32-grade, including operands far below f16's normal range
+    (scale 1e-4: most |a| < 6.1e-5, h0 subnormal or zero, the scaled h1 carries them) and large ones (scale 20: up to ~1e4; the
+    format's documented limit is f16's 65504), with heavy-tailed magnitudes; bias / ReLU / residual / row_div epilogue and the InstanceNorm statistics of the result included."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, K, generator=g)) * scale).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias, res = torch.randn(N, generator=g).cuda() * scale, (torch.randn(M, N, generator=g) * scale).cuda()
+    div = (torch.randint(1, 40, (M,), generator=g).float()).cuda()
+    sw = ops.SplitWeight(w, 'nk')
+    assert ops.f16_pair_ok(M, N, K), 'shape not served by the row-strip kernel'
+    lens = [M // 3, M - M // 3 - 7, 7]
+    seg = seg_of(lens)
+    ref = a.double() @ w.double().t() / div.double()[:, None] + bias.double() + res.double()
+    prev = ops.use_f16_pair
+    errs = {}
+    try:
+        for mode in (False, True):
+            ops.use_f16_pair = mode
+            out, st = ops.gemm(a, sw, bias=bias, row_div=div, residual=res, want_stats=(seg, max(lens)))
+            errs[mode] = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+            if mode:
+                o = 0
+                for c, n in enumerate(lens):
+                    blk = ref[o:o + n]; o += n
+                    assert ((st[c, :, 0].double() - blk.mean(0)).abs().max() / ref.abs().max()).item() < 2e-6
+    finally:
+        ops.use_f16_pair = prev
+    print(f'gemm M {M} N {N} K {K} scale {scale:g}: max rel err bf16x3 {errs[False]:.2e}, f16 pair {errs[True]:.2e}')
+    assert errs[True] < 3e-6 and errs[True] < 8 * max(errs[False], 2e-7)
+
+
 def test_procrustes_vs_oracle():
     from oracle import regtr_ref
     from regtr_amd.se3 import compute_rigid_transform
