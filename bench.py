@@ -505,9 +505,10 @@ def main():
             a = measure_attention(model, fwd_batch, cfg.nhead, cfg.d_embed, cfg.num_encoder_layers)
             peak = MFMA_BF16_PEAK_TFS
             att = {'bound': 'mfma', 'achieved': a['achieved_TFs'], 'peak': peak, 'unit': 'TFLOP/s', 'frac': a['achieved_TFs'] / peak,
-                   'traffic': None, 'detail': dict(a, operands={'fp32': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'fp32x3': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
+                   'traffic': None, 'detail': dict(a, operands={'fp32': 'f16 pair split (3 MFMAs per product, float32-grade)' if model.transformer_encoder.layers[0].attn_precision == 3 else 'bf16x3 split (6 MFMAs per product, float32-grade)',
+                                                               'fp32x3': 'bf16x3 split (6 MFMAs per product, float32-grade)', 'bf16x2': 'bf16x3 split',
                                                                'bf16': 'plain bf16 (1 MFMA per product)'}[dtype],
-                                                   peak_note='dense bf16 MFMA peak; the split mode issues 6x the algorithmic flops')}
+                                                   peak_note='dense bf16 / f16 MFMA peak; the split modes issue 6x (bf16x3) / 3x (f16 pair) the algorithmic flops')}
             # the dominant kernel of the configuration leads: KPConv gather (HBM) for 3DMatch-size pairs, attention (MFMA) for ModelNet
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att

@@ -53,7 +53,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 6
+#define REGTR_ABI_VERSION 7
 int regtr_abi_version(void);
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
@@ -206,8 +206,8 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
 /* The f16 pair operand format (n_planes = 4 of regtr_gemm_x3): x = h0 + h1 / 2048, h0 = f16(x), h1 = f16((x - h0) * 2048) -- 22 mantissa
  * bits in two planes; a product is three v_mfma_f32_32x32x16_f16 (the two low terms in a second, scaled accumulator) at float32-grade
  * accuracy (error vs float64 within 3x of the six-term bf16 split's on RegTR's shapes), half the matrix-pipe work of the bf16 split.
- * Operands must stay below 65504 in magnitude.  Served by the row-strip kernel only: regtr_gemm_x3_f16_supported(M, N, K). */
-int regtr_gemm_x3_f16_supported(int M, int N, int K);
+ * Operands must stay below 65504 in magnitude.  Served by the row-strip kernel only: regtr_gemm_x3_f16_supported(M, N, K, with_stats). */
+int regtr_gemm_x3_f16_supported(int M, int N, int K, int with_stats);      /* with_stats: the call passes stat_partial */
 size_t regtr_gemm_split_weights_f16_bytes(int N, int K);
 int regtr_gemm_split_weights_f16(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
@@ -284,8 +284,10 @@ int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale
 /* ---- attention + pose -------------------------------------------------------------------------------------- */
 
 /* softmax(q k^T * scale) v per head on packed clouds: cloud c's rows attend the rows of cloud kv_of[c]; head_dim = 32.
- * precision: 0 = float32-grade on the bf16 matrix cores (every operand split exactly into three bf16, six MFMAs per product;
- * default), 1 = plain bf16 operands with float32 softmax / accumulation (cfg.compute_dtype 'bf16'), 2 = exact-f32 MFMA. */
+ * precision: 0 = float32-grade on the bf16 matrix cores (every operand split exactly into three bf16, six MFMAs per product),
+ * 1 = plain bf16 operands with float32 softmax / accumulation (cfg.compute_dtype 'bf16'), 2 = exact-f32 MFMA, 3 = float32-grade by the
+ * f16 pair split (x = h0 + h1 / 2048: two planes, three MFMAs per product, a scaled second accumulator; operands below 65504 --
+ * q, k, v are projections of LayerNorm outputs, the probabilities are <= 1; what cfg.compute_dtype 'fp32' uses). */
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
                   int precision, void* stream);

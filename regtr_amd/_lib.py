@@ -20,7 +20,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 6          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 7          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -51,7 +51,7 @@ SIGNATURES = {
     'regtr_gemm_x3_preferred': (_I, [_I, _I, _I]),
     'regtr_gemm_split_weights_bytes': (_Z, [_I, _I]),
     'regtr_gemm_split_weights': (_I, [_P, _I, _I, _I, _I, _P, _P]),
-    'regtr_gemm_x3_f16_supported': (_I, [_I, _I, _I]),
+    'regtr_gemm_x3_f16_supported': (_I, [_I, _I, _I, _I]),
     'regtr_gemm_split_weights_f16_bytes': (_Z, [_I, _I]),
     'regtr_gemm_split_weights_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'regtr_gemm_x3_ws_bytes': (_Z, [_I, _I, _I]),

@@ -199,10 +199,28 @@ __device__ __forceinline__ unsigned bf_pack(float a, float b)
     v.x = (__bf16)a; v.y = (__bf16)b;
     return __builtin_bit_cast(unsigned, v);
 }
+// F16 (NP = 2): the f16 pair of gemm_x3.hip -- x = h0 + h1 / 2048, h0 = f16(x), h1 = f16((x - h0) * 2048): 22 mantissa bits in two planes,
+// three MFMA terms per product (the two low ones in a second accumulator, scaled by 1 / 2048 where it is read)
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
+constexpr float MHA_F16_SCALE = 2048.f;
+__device__ __forceinline__ unsigned f16_pack(float a, float b)
+{
+    f16x2v v;
+    v.x = (_Float16)a; v.y = (_Float16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
 // (a, b) -> NP packed bf16 pairs; for NP = 3: a = a0 + a1 + a2 exactly (likewise b)
-template <int NP>
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void bf_split2(float a, float b, unsigned (&p)[NP])
 {
+    if constexpr (F16) {
+        static_assert(NP == 2, "the f16 pair has two planes");
+        p[0] = f16_pack(a, b);
+        const f16x2v h = __builtin_bit_cast(f16x2v, p[0]);
+        p[1] = f16_pack((a - (float)h.x) * MHA_F16_SCALE, (b - (float)h.y) * MHA_F16_SCALE);
+        return;
+    }
     p[0] = bf_pack(a, b);
     if (NP > 1) {
         const float ra = a - __uint_as_float(p[0] << 16), rb = b - __uint_as_float(p[0] & 0xffff0000u);
@@ -211,12 +229,12 @@ __device__ __forceinline__ void bf_split2(float a, float b, unsigned (&p)[NP])
     }
 }
 // 8 floats -> NP fragments of 8 bf16
-template <int NP>
+template <int NP, bool F16 = false>
 __device__ __forceinline__ void bf_split8(const float (&x)[8], bf16x8 (&f)[NP])
 {
     unsigned w[4][NP];
 #pragma unroll
-    for (int i = 0; i < 4; i++) bf_split2<NP>(x[2 * i], x[2 * i + 1], w[i]);
+    for (int i = 0; i < 4; i++) bf_split2<NP, F16>(x[2 * i], x[2 * i + 1], w[i]);
 #pragma unroll
     for (int p = 0; p < NP; p++) f[p] = __builtin_bit_cast(bf16x8, make_uint4(w[0][p], w[1][p], w[2][p], w[3][p]));
 }
@@ -236,7 +254,15 @@ __device__ __forceinline__ floatx16 bf_mma(const bf16x8 (&a)[NP], const bf16x8 (
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
 }
 
-template <int NP>
+// f16 pair product: hi += a0 b0, lo += a1 b0 + a0 b1 (alternating accumulators)
+__device__ __forceinline__ void f16_mma(const bf16x8 (&a)[2], const bf16x8 (&b)[2], floatx16& hi, floatx16& lo)
+{
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a[1]), __builtin_bit_cast(f16x8v, b[0]), lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a[0]), __builtin_bit_cast(f16x8v, b[0]), hi, 0, 0, 0);
+    lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a[0]), __builtin_bit_cast(f16x8v, b[1]), lo, 0, 0, 0);
+}
+
+template <int NP, bool F16 = false>
 __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
 {
     __shared__ __align__(16) unsigned char Ks[2][NP][TK * BROW];      // [buffer][plane][key][32 channels]
@@ -269,7 +295,7 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
         for (int ks = 0; ks < 2; ks++) {
             const float x[8] = {qv[ks][0].x * scl, qv[ks][0].y * scl, qv[ks][0].z * scl, qv[ks][0].w * scl,
                                 qv[ks][1].x * scl, qv[ks][1].y * scl, qv[ks][1].z * scl, qv[ks][1].w * scl};
-            bf_split8<NP>(x, qf[ks]);
+            bf_split8<NP, F16>(x, qf[ks]);
         }
     }
 
@@ -301,12 +327,12 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
     };
     auto stage = [&](const KV& r, int buf) {
         unsigned a[NP], b[NP];
-        bf_split2<NP>(r.k.x, r.k.y, a);
-        bf_split2<NP>(r.k.z, r.k.w, b);
+        bf_split2<NP, F16>(r.k.x, r.k.y, a);
+        bf_split2<NP, F16>(r.k.z, r.k.w, b);
 #pragma unroll
         for (int p = 0; p < NP; p++) *(uint2*)(&Ks[buf][p][k_dst]) = make_uint2(a[p], b[p]);
-        bf_split2<NP>(r.v0.x, r.v1.x, a);             // (key 2u, key 2u + 1) of channel sd2
-        bf_split2<NP>(r.v0.y, r.v1.y, b);             // ... of channel sd2 + 1
+        bf_split2<NP, F16>(r.v0.x, r.v1.x, a);        // (key 2u, key 2u + 1) of channel sd2
+        bf_split2<NP, F16>(r.v0.y, r.v1.y, b);        // ... of channel sd2 + 1
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             *(unsigned*)(&Vt[buf][p][v_dst[0]]) = a[p];
@@ -314,9 +340,9 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
         }
     };
 
-    floatx16 o;
+    floatx16 o, o_lo;                                  // (o_lo: the f16 pair's scaled low terms of O)
 #pragma unroll
-    for (int r = 0; r < 16; r++) o[r] = 0.f;
+    for (int r = 0; r < 16; r++) { o[r] = 0.f; o_lo[r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
     unsigned f_off[2];
 #pragma unroll
@@ -353,17 +379,22 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
         fetch(rnew, kt + 2 * TK);
         MHA_STAMP(1);
         if (wave_live) {
-            floatx16 sc;
+            floatx16 sc, sc_lo;
 #pragma unroll
-            for (int r = 0; r < 16; r++) sc[r] = 0.f;
+            for (int r = 0; r < 16; r++) { sc[r] = 0.f; sc_lo[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 bf16x8 kf[NP];
 #pragma unroll
                 for (int p = 0; p < NP; p++) kf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Ks[buf][p][f_off[ks]]));
                 MHA_PRIO(2);
-                sc = bf_mma<NP>(kf, qf[ks], sc);
+                if constexpr (F16) f16_mma(kf, qf[ks], sc, sc_lo);
+                else sc = bf_mma<NP>(kf, qf[ks], sc);
                 MHA_PRIO(0);
+            }
+            if constexpr (F16) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sc[r] += sc_lo[r] * (1.0f / MHA_F16_SCALE);
             }
             MHA_STAMP(2);
             float mx = -INFINITY;
@@ -386,18 +417,19 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; r++) o[r] *= alpha;
+            for (int r = 0; r < 16; r++) { o[r] *= alpha; if (F16) o_lo[r] *= alpha; }
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 float x[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) x[j] = pr[8 * ks + j];
                 bf16x8 pf[NP], vf[NP];
-                bf_split8<NP>(x, pf);
+                bf_split8<NP, F16>(x, pf);
 #pragma unroll
                 for (int p = 0; p < NP; p++) vf[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(&Vt[buf][p][f_off[ks]]));
                 MHA_PRIO(2);
-                o = bf_mma<NP>(vf, pf, o);
+                if constexpr (F16) f16_mma(vf, pf, o, o_lo);
+                else o = bf_mma<NP>(vf, pf, o);
                 MHA_PRIO(0);
             }
             MHA_STAMP(3);
@@ -418,6 +450,10 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
                (int)blockIdx.z, (int)blockIdx.x, wave, (int)wave_live, nk, pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], clock64() - pstart);
 #endif
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[r] += o_lo[r] * (1.0f / MHA_F16_SCALE);
+    }
     const int qrow = q0 + l31;
     if (wave_live && qrow < q_end) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;   // empty key set -> zeros
@@ -554,14 +590,15 @@ extern "C" {
 // q, k, v: [N_total, *] row-major views (leading dims ldq/ldk/ldv) holding n_heads * 32 columns each;
 // out [N_total, ldo].  seg_off [n_clouds + 1] and kv_of [n_clouds] live on the device.
 // max_len = longest query segment (host-known bound used for the launch grid).
-// precision: 0 = float32-grade on the bf16 matrix cores (three-way split operands, default), 1 = plain bf16 operands
-// (float32 softmax / accumulation), 2 = the exact-f32 MFMA kernel (one wave per 32-query tile; the A/B reference).
+// precision: 0 = float32-grade on the bf16 matrix cores (three-way split operands), 1 = plain bf16 operands
+// (float32 softmax / accumulation), 2 = the exact-f32 MFMA kernel (one wave per 32-query tile; the A/B reference), 3 = float32-grade by
+// the f16 pair split (two planes, three MFMA terms; operands below 65504: q, k, v are projections of LayerNorm outputs, p <= 1).
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
                   int precision, void* stream)
 {
     if (!q || !k || !v || !out || !seg_off || !kv_of || n_clouds < 1 || n_heads < 1 || max_len < 0) return RG_ERR_ARG;
-    if (head_dim != HD || precision < 0 || precision > 2) return RG_ERR_ARG;
+    if (head_dim != HD || precision < 0 || precision > 3) return RG_ERR_ARG;
     if ((ldq | ldk | ldv | ldo) % 4 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
     MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
@@ -570,7 +607,7 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
     // four times as many workgroups on the chip and stages K / V without the split -- 32 us against 56 us per launch at one
     // 3DMatch pair.  Both are float32-grade, so precision 0 may take either.
     const bool small = (long long)rg_cdiv(max_len, BW * TQ) * n_heads * n_clouds < 512;
-    if (precision == 2 || (precision == 0 && small)) {
+    if (precision == 2 || ((precision == 0 || precision == 3) && small)) {
         const dim3 grid(rg_cdiv(max_len, TQ), n_heads, n_clouds);
         // very small launches (one pair: ~200 query tiles on 256 CUs): four waves split the keys of a tile
         if ((long long)grid.x * grid.y * grid.z <= 1024 && max_len > 4 * TK) k_mha_fwd<4><<<grid, 4 * RG_WAVE, 0, st>>>(g);
@@ -580,6 +617,7 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
         if ((ldv % 2) || ((uintptr_t)v % 8)) return RG_ERR_ARG;
         const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);
         if (precision == 0) k_mha_fwd_bf16<3><<<grid, BW * RG_WAVE, 0, st>>>(g);
+        else if (precision == 3) k_mha_fwd_bf16<2, true><<<grid, BW * RG_WAVE, 0, st>>>(g);
         else k_mha_fwd_bf16<1><<<grid, BW * RG_WAVE, 0, st>>>(g);
     }
     RG_RETURN_IF_LAUNCH_FAILED();

@@ -748,7 +748,8 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     // rows two tiles ahead, every LDS-DMA instruction issued between MFMAs), with TWO planes per operand and THREE MFMAs per column
     // block -- a0 w1 into the low accumulator, a0 w0 into the high one, a1 w0 into the low one -- and the f16 split of the next step's A
     // piece (cvt_pk / two cvt back / two sub / two mul / cvt_pk per float pair) behind them.
-    static_assert(CW == 2 && NQ <= 2, "the f16 pair hand loop is written for 128 x 64 tiles");
+    static_assert((CW == 2 || CW == 4) && NQ <= 4, "the f16 pair hand loop is written for 128 x 64 and 128 x 128 tiles");
+    constexpr int PJ = 4 / CW;                 // float pairs of the next A piece split behind each column block
     unsigned vb[2], va[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ks++) {
@@ -772,9 +773,9 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
         fa[SET][p_] = __builtin_bit_cast(bf16x8, make_uint4(pl[SET][p_][0], pl[SET][p_][1], pl[SET][p_][2], pl[SET][p_][3])); } while (0)
 #define X3F_BLOCK(J, FS, CS, H1, H2) do { \
         const bf16x8 b0_ = __builtin_bit_cast(bf16x8, fbq[CS][0]), b1_ = __builtin_bit_cast(bf16x8, fbq[CS][1]); \
-        x3h_mfma_f16(acc_lo[J], fa[FS][1], b0_); X3F_PAIR_A((FS) ^ 1, 2 * (J)); \
-        x3h_mfma_f16(acc[J], fa[FS][0], b0_); X3F_PAIR_B((FS) ^ 1, 2 * (J)); H1; \
-        x3h_mfma_f16(acc_lo[J], fa[FS][0], b1_); X3F_PAIR_A((FS) ^ 1, 2 * (J) + 1); X3F_PAIR_B((FS) ^ 1, 2 * (J) + 1); H2; } while (0)
+        x3h_mfma_f16(acc_lo[J], fa[FS][1], b0_); X3F_PAIR_A((FS) ^ 1, PJ * (J)); \
+        x3h_mfma_f16(acc[J], fa[FS][0], b0_); X3F_PAIR_B((FS) ^ 1, PJ * (J)); H1; \
+        x3h_mfma_f16(acc_lo[J], fa[FS][0], b1_); if (PJ == 2) { X3F_PAIR_A((FS) ^ 1, PJ * (J) + 1); X3F_PAIR_B((FS) ^ 1, PJ * (J) + 1); } H2; } while (0)
 #define X3F_DB(I) do { if ((I) < NQ && more_b) x3_asm_dma16((const void*)(b_src[(I) < NQ ? (I) : 0] + (kt + 1) * XBK), b_wave + b_slot * B_BYTES + (I) * 1024u); } while (0)
 #define X3F_DA(I) do { if (more_a) x3_asm_dma16((const void*)(a_src[I] + (kt + 2) * XBK), a_wave + a_tgt * A_BYTES + (I) * 1024u); } while (0)
 #define X3F_VM(N) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory")
@@ -798,15 +799,29 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
         const unsigned a_tgt = a_read ^ 1u;                         // tile kt's own rows were read (raw) half a tile ago: their slot takes tile kt + 2
         X3F_FB(0, 0, 0);
         // step 0 (fa[0]); behind it: the split of this tile's second A piece (raw[1] -> fa[1]) and the weight DMAs of tile kt + 1
-        X3F_FB(0, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 0, 0, X3F_DB(0), X3F_DB(1));
-        X3F_FB(1, 0, 0); X3H_LGKM(2); X3F_BLOCK(1, 0, 1, (void)0, (void)0);
+        if constexpr (CW == 2) {
+            X3F_FB(0, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 0, 0, X3F_DB(0), X3F_DB(1));
+            X3F_FB(1, 0, 0); X3H_LGKM(2); X3F_BLOCK(1, 0, 1, (void)0, (void)0);
+        } else {
+            X3F_FB(0, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 0, 0, X3F_DB(0), X3F_DB(1));
+            X3F_FB(0, 2, 0); X3H_LGKM(2); X3F_BLOCK(1, 0, 1, X3F_DB(2), X3F_DB(3));
+            X3F_FB(0, 3, 1); X3H_LGKM(2); X3F_BLOCK(2, 0, 0, (void)0, (void)0);
+            X3F_FB(1, 0, 0); X3H_LGKM(2); X3F_BLOCK(3 % CW, 0, 1, (void)0, (void)0);
+        }
         X3F_PACK(1);
         if (more_b) X3F_VM(NQ); else X3F_VM(0);                     // this wave's rows of tile kt + 1 have landed (issued a tile ago; only W(kt + 1) is younger)
         X3F_RAW(0, 0);
         X3F_RAW(1, 1);
         // step 1 (fa[1]); behind it: the split of the next tile's first A piece (raw[0] -> fa[0]) and the own-row DMAs of tile kt + 2
-        X3F_FB(1, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 1, 0, X3F_DA(0), X3F_DA(1));
-        X3H_LGKM(0); X3F_BLOCK(1, 1, 1, X3F_DA(2), X3F_DA(3));
+        if constexpr (CW == 2) {
+            X3F_FB(1, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 1, 0, X3F_DA(0), X3F_DA(1));
+            X3H_LGKM(0); X3F_BLOCK(1, 1, 1, X3F_DA(2), X3F_DA(3));
+        } else {
+            X3F_FB(1, 1, 1); X3H_LGKM(2); X3F_BLOCK(0, 1, 0, X3F_DA(0), (void)0);
+            X3F_FB(1, 2, 0); X3H_LGKM(2); X3F_BLOCK(1, 1, 1, X3F_DA(1), (void)0);
+            X3F_FB(1, 3, 1); X3H_LGKM(2); X3F_BLOCK(2, 1, 0, X3F_DA(2), (void)0);
+            X3H_LGKM(0); X3F_BLOCK(3 % CW, 1, 1, X3F_DA(3), (void)0);
+        }
         X3F_PACK(0);
         if (more_a) X3F_VM(4); else X3F_VM(0);                      // W(kt + 1) has landed (the rows of tile kt + 2 stay in flight)
         X3F_BARRIER();
@@ -1166,13 +1181,23 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
     return RG_OK;
 }
 
-// f16 pair format (regtr_gemm_x3 with n_planes = 4): served by the row-strip kernel only -- N a multiple of 64, K a multiple of 32, and
-// a tile plan that takes the strip form (tall problems); no folded A operand
-int regtr_gemm_x3_f16_supported(int M, int N, int K)
+// Tile plan of the f16 pair format (regtr_gemm_x3 with n_planes = 4), served by the row-strip kernel only: the bf16 plan where that takes
+// the strip form; else -- without the statistics epilogue, whose slot height is tied to the bf16 plan -- 128 x 64 strips as soon as
+// there are 512 of them (the 37.9 k-token out-projection of the cross-encoder: 1184 strips; the bf16 kernel prefers 64 x 64 tiles there)
+static bool x3_plan_f16(int M, int N, int K, bool with_stats, X3Plan& p)
 {
-    if (!regtr_gemm_x3_supported(M, N, K) || N < 64 || K % XBK) return 0;
-    const X3Plan p = x3_plan(M, N, K);
-    return (p.strip && p.k_chunk % XBK == 0) ? 1 : 0;
+    if (!regtr_gemm_x3_supported(M, N, K) || N < 64 || K % XBK) return false;
+    p = x3_plan(M, N, K);
+    if (p.strip && p.k_chunk % XBK == 0) return true;
+    if (with_stats || p.splits > 1 || (long long)rg_cdiv(M, 128) * (N / 64) < 512) return false;
+    p.tile = 1; p.strip = true;
+    return true;
+}
+
+int regtr_gemm_x3_f16_supported(int M, int N, int K, int with_stats)
+{
+    X3Plan p;
+    return x3_plan_f16(M, N, K, with_stats != 0, p) ? 1 : 0;
 }
 
 size_t regtr_gemm_split_weights_f16_bytes(int N, int K)
@@ -1223,13 +1248,15 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     // n_planes: 1 | 2 | 3 bf16 planes (regtr_gemm_split_weights); 4 = the f16 pair of regtr_gemm_split_weights_f16 (three MFMA terms at
     // float32-grade accuracy; row-strip kernel only: regtr_gemm_x3_f16_supported)
     if (n_planes < 1 || n_planes > 4 || ((n_planes == 1 || n_planes == 2) && (a_stats || stat_partial)) || (n_planes == 4 && a_stats)) return RG_ERR_ARG;
-    if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K)) return RG_ERR_ARG;
+    if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K, stat_partial != nullptr)) return RG_ERR_ARG;
     if (N == 32 && a_stats) return RG_ERR_ARG;               // the thin case exists on the row-strip kernel only
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
     X3Plan p = x3_plan(M, N, K);
-    if (n_planes == 4 && p.tile == 0) p.tile = 1;           // the f16 pair's two accumulator sets fit the register file at 128 x 64 only (128 x 128: 256 VGPRs + spills)
+    if (n_planes == 4) x3_plan_f16(M, N, K, stat_partial != nullptr, p);
+    static const int f16_cw4 = (getenv("REGTR_F16_CW4") && *getenv("REGTR_F16_CW4")) ? atoi(getenv("REGTR_F16_CW4")) : 1;   // development: A/B runs
+    if (n_planes == 4 && p.tile == 0 && !f16_cw4) p.tile = 1;
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
     if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
@@ -1247,8 +1274,8 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
         else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                else k_gemm_x3<MW_, NW_, WM_, WN_, false, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } while (0)
 #define X3D_LAUNCH(MW_, CW_, AR_) do { \
-        if (n_planes == 4) { if (stat_partial) k_gemm_x3d<4, 2, 2, true, 2, 1><<<grid, 256, 0, st>>>(g); \
-                             else k_gemm_x3d<4, 2, 2, false, 2, 1><<<grid, 256, 0, st>>>(g); } \
+        if (n_planes == 4) { if (stat_partial) k_gemm_x3d<4, CW_, 2, true, 2, 1><<<grid, 256, 0, st>>>(g); \
+                             else k_gemm_x3d<4, CW_, 2, false, 2, 1><<<grid, 256, 0, st>>>(g); } \
         else if (n_planes == 1) k_gemm_x3d<4, CW_, 2, false, 1><<<grid, 256, 0, st>>>(g); \
         else if (n_planes == 2) k_gemm_x3d<4, CW_, 2, false, 2><<<grid, 256, 0, st>>>(g); \
         else if (stat_partial) k_gemm_x3d<MW_, CW_, AR_, true><<<grid, 64 * MW_, 0, st>>>(g); \

@@ -157,12 +157,13 @@ class f16_pair:
         use_f16_pair = self.prev
 
 
-def f16_pair_ok(M, N, K):
-    v = _f16_shape.get((M, N, K))
+def f16_pair_ok(M, N, K, with_stats=False):
+    key = (M, N, K, bool(with_stats))
+    v = _f16_shape.get(key)
     if v is None:
         if len(_f16_shape) > 4096:
             _f16_shape.clear()
-        v = _f16_shape[(M, N, K)] = bool(_lib.lib().regtr_gemm_x3_f16_supported(M, N, K))
+        v = _f16_shape[key] = bool(_lib.lib().regtr_gemm_x3_f16_supported(M, N, K, 1 if with_stats else 0))
     return v
 
 
@@ -222,7 +223,7 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
             ti = tile_segments(seg_rows, M, x3_rows)
         pl, npl = sw.planes, int(planes)
-        if use_f16_pair and npl >= 2 and a_stats is None and f16_pair_ok(M, N, K):
+        if use_f16_pair and npl >= 2 and a_stats is None and f16_pair_ok(M, N, K, R > 0):
             pl, npl = sw.planes16, 4
         check(L.regtr_gemm_x3(raw(a), lda, bptr(pl), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,

@@ -133,7 +133,7 @@ class RegTR(nn.Module):
         if dt not in ('fp32', 'fp32x3', 'bf16', 'bf16x2'):
             raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, fp32x3, bf16x2 or bf16')
         encoder_layer.gemm_planes = {'fp32': 2, 'fp32x3': 3, 'bf16x2': 2, 'bf16': 1}[dt]
-        encoder_layer.attn_precision = 1 if dt == 'bf16' else 0
+        encoder_layer.attn_precision = 1 if dt == 'bf16' else (3 if (dt == 'fp32' and ops.f16_pair_default) else 0)      # ops.mha's codes
         self._f16_pair = dt in ('fp32', 'bf16') and ops.f16_pair_default      # ('bf16': the encoder / head GEMMs, which stay float32-grade)
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)

@@ -492,13 +492,13 @@ def test_layernorm_posemb_vs_oracle():
     assert (pe - regtr_ref.pos_embed_sine(xyz, 256, 1.0)).abs().max() < 2e-5
 
 
-@pytest.mark.parametrize('precision,tol', [(0, 2e-5), (2, 2e-5), (1, 6e-2)])
+@pytest.mark.parametrize('precision,tol', [(0, 2e-5), (2, 2e-5), (1, 6e-2), (3, 2e-5)])
 @pytest.mark.parametrize('lens', [[412, 339], [601, 612], [33, 1, 64, 7], [2100, 1900], [130, 0, 5, 129],
                                   [150, 97, 260, 33] * 10 + [170, 0, 129, 64] * 10])      # the last one: enough workgroups for the 4-wave kernel
 def test_mha_vs_oracle(lens, precision, tol):
     """self- and cross-attention cores on packed ragged clouds vs the plain softmax(QK^T)V restatement in float64:
-    precision 0 (bf16x3 split MFMA, the default) and 2 (exact-f32 MFMA) at float32 accuracy, 1 (plain bf16 operands) at
-    bf16 accuracy; an empty partner cloud gives zeros."""
+    precision 0 (bf16x3 split MFMA), 3 (f16 pair split, compute_dtype 'fp32') and 2 (exact-f32 MFMA) at float32 accuracy, 1 (plain bf16
+    operands) at bf16 accuracy; an empty partner cloud gives zeros."""
     ops = _ops()
     g = torch.Generator().manual_seed(sum(lens))
     N, E, H = sum(lens), 256, 8
