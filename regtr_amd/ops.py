@@ -141,6 +141,7 @@ class SplitWeight:
 # REGTR_F16_PAIR=0); use_f16_pair: the switch gemm() reads, set per forward by RegTR (`with ops.f16_pair(flag)`) and by tests.
 f16_pair_default = os.environ.get('REGTR_F16_PAIR', '1') != '0'
 use_f16_pair = False
+f16_range_log = None      # a list: gemm() records (M, N, K, max |A|, max |W|) of every f16-pair launch (the format's operands must stay below 65504)
 _f16_shape = {}
 
 
@@ -225,6 +226,8 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         pl, npl = sw.planes, int(planes)
         if use_f16_pair and npl >= 2 and a_stats is None and f16_pair_ok(M, N, K, R > 0):
             pl, npl = sw.planes16, 4
+            if f16_range_log is not None:      # tests / audits: the largest operand magnitude handed to the f16 pair format (synchronises)
+                f16_range_log.append((M, N, K, float(a.abs().max()) if M else 0.0, float(sw.kn.abs().max())))
         check(L.regtr_gemm_x3(raw(a), lda, bptr(pl), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,

@@ -132,7 +132,7 @@ class TransformerCrossEncoder(nn.Module):
     # pair per forward the host is the bound and these are 72 of its ~280 launches (csrc/cross_encoder.hip).
     def _one_call_ok(self, x, pe):
         l0 = self.layers[0]
-        if not (ops.use_one_call_cross_encoder and ops.mha_records is None and not ops.force_f32_gemm and x.dim() == 2 and x.is_contiguous()
+        if not (ops.use_one_call_cross_encoder and ops.mha_records is None and ops.f16_range_log is None and not ops.force_f32_gemm and x.dim() == 2 and x.is_contiguous()
                 and x.data_ptr() % 16 == 0 and (pe is None or pe.is_contiguous())):
             return False
         for layer in self.layers:

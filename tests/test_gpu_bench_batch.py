@@ -79,3 +79,24 @@ def test_lomatch_pairs_vs_oracle_and_ragged_forward():
     tail = model({'src_xyz': batch['src_xyz'][8:], 'tgt_xyz': batch['tgt_xyz'][8:]})
     assert (head['pose'] - out['pose'][:, :8]).abs().max() < 1e-4 and (tail['pose'] - out['pose'][:, 8:]).abs().max() < 1e-4
     assert torch.equal(tail['src_kp'][0], out['src_kp'][8])
+
+
+def test_f16_pair_operand_range_on_the_bench_workload():
+    """The f16 pair format (cfg.compute_dtype 'fp32' on the row-strip GEMM) needs operands below f16's 65504.  Audit on 16 pairs of the
+    benchmark workload: every launch that took the format, the largest |A| and |W| it was handed -- InstanceNorm / LayerNorm outputs,
+    their gathered kernel-point sums and ReLU'd projections of those; a factor > 50 below the limit with the seeded weights."""
+    import bench
+    from regtr_amd import ops
+    dev = torch.device('cuda', 0)
+    cfg, model, pairs, batch = bench.build_workload('3dmatch', 16, 20000, False, 0, dev, 'fp32')
+    ops.f16_range_log = log = []
+    try:
+        out = model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
+        torch.cuda.synchronize()
+    finally:
+        ops.f16_range_log = None
+    assert torch.isfinite(out['pose']).all()
+    assert len(log) >= 20, 'the batched forward should route its tall contractions through the f16 pair format'
+    worst_a, worst_w = max(r[3] for r in log), max(r[4] for r in log)
+    print(f'f16 pair: {len(log)} launches, largest |A| {worst_a:.1f} (shape {max(log, key=lambda r: r[3])[:3]}), largest |W| {worst_w:.2f}; limit 65504')
+    assert worst_a < 65504 / 50 and worst_w < 65504 / 50
