@@ -94,9 +94,11 @@ __device__ __forceinline__ void x3_split2_f16(float a, float b, unsigned& p0, un
 
 // NP = bf16 planes per operand: 3 = float32-grade (six MFMA terms, the default); 2 = the three leading terms a0 w0 + a0 w1 +
 // a1 w0 (relative error ~2^-16 per product); 1 = plain bf16 operands (cfg.compute_dtype 'bf16').
-template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT, int NP = 3>      // MW x NW waves, wave tile (32 WM) x (32 WN)
+// FMT = 1 (NP = 2): the f16 pair format -- two f16 planes per operand, three MFMA terms, the two low ones in a second accumulator set
+template <int MW, int NW, int WM, int WN, bool STATS, bool SOUT, int NP = 3, int FMT = 0>      // MW x NW waves, wave tile (32 WM) x (32 WN)
 __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x3(X3Args g)
 {
+    static_assert(FMT == 0 || (FMT == 1 && NP == 2), "the f16 pair format has two planes");
     constexpr int NT = 64 * MW * NW, RPP = NT / 8; // threads; A rows staged per pass (8 float4 per row)
     constexpr int BM = 32 * WM * MW, BN = 32 * WN * NW;
     constexpr int AV = BM / RPP;                  // float4 of A per thread per tile
@@ -203,9 +205,9 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
             }
             const bool ok = a_ok[i] && ra_kin;
             v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-            unsigned p0a, p1a, p2a, p0b, p1b, p2b;
-            x3_split2(v.x, v.y, p0a, p1a, p2a);
-            x3_split2(v.z, v.w, p0b, p1b, p2b);
+            unsigned p0a, p1a, p2a = 0, p0b, p1b, p2b = 0;
+            if (FMT == 1) { x3_split2_f16(v.x, v.y, p0a, p1a); x3_split2_f16(v.z, v.w, p0b, p1b); }
+            else { x3_split2(v.x, v.y, p0a, p1a, p2a); x3_split2(v.z, v.w, p0b, p1b, p2b); }
             unsigned char* dst = As + a_st_off + i * RPP * XROW;
             *(uint2*)(dst) = make_uint2(p0a, p0b);
             if (NP > 1) *(uint2*)(dst + BM * XROW) = make_uint2(p1a, p1b);
@@ -228,12 +230,13 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     };
 
     floatx16 acc[WM][WN];
+    floatx16 acc_lo[FMT == 1 ? WM : 1][FMT == 1 ? WN : 1];     // f16 pair: the scaled low terms
 #pragma unroll
     for (int i = 0; i < WM; i++)
 #pragma unroll
         for (int j = 0; j < WN; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; if (FMT == 1) acc_lo[FMT == 1 ? i : 0][FMT == 1 ? j : 0][r] = 0.f; }
 
     // fragment byte offset of this lane within a 32-row block: row l31, logical chunk (2 ks + hi)
     unsigned f_off[XBK / 16];
@@ -259,10 +262,19 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
             _Pragma("unroll") for (int i = 0; i < WM; i++)                                                           \
                 _Pragma("unroll") for (int j = 0; j < WN; j++)                                                       \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA], fb[j][PB], acc[i][j], 0, 0, 0);
+#define X3_TERM_F16(ACC, PA, PB)                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < WM; i++)                                                           \
+                _Pragma("unroll") for (int j = 0; j < WN; j++)                                                       \
+                    ACC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, fa[i][PA]),      \
+                                                                       __builtin_bit_cast(x3_f16x8, fb[j][PB]), ACC[i][j], 0, 0, 0);
+            if constexpr (FMT == 1) { X3_TERM_F16(acc_lo, 1, 0) X3_TERM_F16(acc, 0, 0) X3_TERM_F16(acc_lo, 0, 1) }
+            else {
             if (NP == 3) { X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) }
             if (NP >= 2) { X3_TERM((NP >= 2 ? 1 : 0), 0) X3_TERM(0, (NP >= 2 ? 1 : 0)) }
             X3_TERM(0, 0)
+            }
 #undef X3_TERM
+#undef X3_TERM_F16
         }
     };
 
@@ -295,6 +307,14 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
         __syncthreads();
     }
 
+    if constexpr (FMT == 1) {                              // f16 pair: fold the scaled low terms in
+#pragma unroll
+        for (int i = 0; i < WM; i++)
+#pragma unroll
+            for (int j = 0; j < WN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] += acc_lo[i][j][r] * (1.0f / X3_F16_SCALE);
+    }
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
 #pragma unroll
     for (int i = 0; i < WM; i++)
@@ -1181,16 +1201,14 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
     return RG_OK;
 }
 
-// Tile plan of the f16 pair format (regtr_gemm_x3 with n_planes = 4), served by the row-strip kernel only: the bf16 plan where that takes
-// the strip form; else -- without the statistics epilogue, whose slot height is tied to the bf16 plan -- 128 x 64 strips as soon as
-// there are 512 of them (the 37.9 k-token out-projection of the cross-encoder: 1184 strips; the bf16 kernel prefers 64 x 64 tiles there)
+// Tile plan of the f16 pair format (regtr_gemm_x3 with n_planes = 4): the bf16 plan (strip or tiled kernel alike); without the
+// statistics epilogue -- whose slot height is tied to the bf16 plan -- a 64 x 64-tile plan becomes 128 x 64 strips as soon as there
+// are 512 of them (the 37.9 k-token out-projection of the cross-encoder: 1184 strips)
 static bool x3_plan_f16(int M, int N, int K, bool with_stats, X3Plan& p)
 {
-    if (!regtr_gemm_x3_supported(M, N, K) || N < 64 || K % XBK) return false;
+    if (!regtr_gemm_x3_supported(M, N, K) || N < 64) return false;
     p = x3_plan(M, N, K);
-    if (p.strip && p.k_chunk % XBK == 0) return true;
-    if (with_stats || p.splits > 1 || (long long)rg_cdiv(M, 128) * (N / 64) < 512) return false;
-    p.tile = 1; p.strip = true;
+    if (!p.strip && !with_stats && p.splits == 1 && K % XBK == 0 && (long long)rg_cdiv(M, 128) * (N / 64) >= 512) { p.tile = 1; p.strip = true; }
     return true;
 }
 
@@ -1247,7 +1265,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     if (tile_info && a_stats && stat_partial && (a_seg_off != stat_seg_off || n_seg != n_stat_seg)) return RG_ERR_ARG;
     // n_planes: 1 | 2 | 3 bf16 planes (regtr_gemm_split_weights); 4 = the f16 pair of regtr_gemm_split_weights_f16 (three MFMA terms at
     // float32-grade accuracy; row-strip kernel only: regtr_gemm_x3_f16_supported)
-    if (n_planes < 1 || n_planes > 4 || ((n_planes == 1 || n_planes == 2) && (a_stats || stat_partial)) || (n_planes == 4 && a_stats)) return RG_ERR_ARG;
+    if (n_planes < 1 || n_planes > 4 || ((n_planes == 1 || n_planes == 2) && (a_stats || stat_partial))) return RG_ERR_ARG;
     if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K, stat_partial != nullptr)) return RG_ERR_ARG;
     if (N == 32 && a_stats) return RG_ERR_ARG;               // the thin case exists on the row-strip kernel only
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
@@ -1257,6 +1275,9 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     if (n_planes == 4) x3_plan_f16(M, N, K, stat_partial != nullptr, p);
     static const int f16_cw4 = (getenv("REGTR_F16_CW4") && *getenv("REGTR_F16_CW4")) ? atoi(getenv("REGTR_F16_CW4")) : 1;   // development: A/B runs
     if (n_planes == 4 && p.tile == 0 && !f16_cw4) p.tile = 1;
+    // (tiled kernel, f16 pair: the 8-wave 128 x 128 tile's two accumulator sets do not fit its 128-register budget -- 128 x 64 instead;
+    //  same 128-row statistics slots)
+    if (n_planes == 4 && p.tile == 0 && (!p.strip || a_stats || K % XBK || p.k_chunk % XBK)) p.tile = 1;
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
     if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
@@ -1267,7 +1288,12 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
     dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * rg_cdiv(N, bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
 #define X3_LAUNCH(MW_, NW_, WM_, WN_) do { \
-        if (n_planes == 1) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+        if (n_planes == 4) { if constexpr (NW_ == 2) { \
+            if (a_stats) { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, true, true, 2, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+                           else k_gemm_x3<MW_, NW_, WM_, WN_, true, false, 2, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \
+            else { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, false, true, 2, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
+                   else k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 2, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } } } \
+        else if (n_planes == 1) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 1><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
         else if (n_planes == 2) k_gemm_x3<MW_, NW_, WM_, WN_, false, false, 2><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
         else if (a_stats) { if (stat_partial) k_gemm_x3<MW_, NW_, WM_, WN_, true, true><<<grid, 64 * MW_ * NW_, 0, st>>>(g); \
                        else k_gemm_x3<MW_, NW_, WM_, WN_, true, false><<<grid, 64 * MW_ * NW_, 0, st>>>(g); } \

@@ -224,7 +224,7 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
             ti = tile_segments(seg_rows, M, x3_rows)
         pl, npl = sw.planes, int(planes)
-        if use_f16_pair and npl >= 2 and a_stats is None and f16_pair_ok(M, N, K, R > 0):
+        if use_f16_pair and npl >= 2 and f16_pair_ok(M, N, K, R > 0):
             pl, npl = sw.planes16, 4
             if f16_range_log is not None:      # tests / audits: the largest operand magnitude handed to the f16 pair format (synchronises)
                 f16_range_log.append((M, N, K, float(a.abs().max()) if M else 0.0, float(sw.kn.abs().max())))
