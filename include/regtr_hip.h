@@ -206,7 +206,7 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
 /* The f16 pair operand format (n_planes = 4 of regtr_gemm_x3): x = h0 + h1 / 2048, h0 = f16(x), h1 = f16((x - h0) * 2048) -- 22 mantissa
  * bits in two planes; a product is three v_mfma_f32_32x32x16_f16 (the two low terms in a second, scaled accumulator) at float32-grade
  * accuracy (error vs float64 within 3x of the six-term bf16 split's on RegTR's shapes), half the matrix-pipe work of the bf16 split.
- * Operands must stay below 65504 in magnitude.  regtr_gemm_x3_f16_supported(M, N, K, with_stats): every regtr_gemm_x3 shape with N >= 64. */
+ * Operands must stay below 65504 in magnitude.  regtr_gemm_x3_f16_supported(M, N, K, with_stats): every shape regtr_gemm_x3 supports. */
 int regtr_gemm_x3_f16_supported(int M, int N, int K, int with_stats);      /* with_stats: the call passes stat_partial */
 size_t regtr_gemm_split_weights_f16_bytes(int N, int K);
 int regtr_gemm_split_weights_f16(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);

@@ -1206,7 +1206,7 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
 // are 512 of them (the 37.9 k-token out-projection of the cross-encoder: 1184 strips)
 static bool x3_plan_f16(int M, int N, int K, bool with_stats, X3Plan& p)
 {
-    if (!regtr_gemm_x3_supported(M, N, K) || N < 64) return false;
+    if (!regtr_gemm_x3_supported(M, N, K)) return false;          // (N = 32: the thin strip form, K a multiple of 32, no folded operand)
     p = x3_plan(M, N, K);
     if (!p.strip && !with_stats && p.splits == 1 && K % XBK == 0 && (long long)rg_cdiv(M, 128) * (N / 64) >= 512) { p.tile = 1; p.strip = true; }
     return true;

@@ -140,6 +140,9 @@ class SplitWeight:
 # instead of six (planes = 3) / three (planes = 2) bf16 terms.  f16_pair_default: what cfg.compute_dtype 'fp32' asks for (A-B runs:
 # REGTR_F16_PAIR=0); use_f16_pair: the switch gemm() reads, set per forward by RegTR (`with ops.f16_pair(flag)`) and by tests.
 f16_pair_default = os.environ.get('REGTR_F16_PAIR', '1') != '0'
+# N = 32 contractions (level 0) on the f16 pair strip kernel: measured 1044 us against 1084 us + 70 us of separate statistics passes on the
+# exact-f32 kernel, 27.71 vs 27.73 ms per forward (gpurun_out/r03_f7) -- both stream the 4.6 GB operand at ~4.4 TB/s; off
+thin_f16_gemm = os.environ.get('REGTR_F16_THIN', '0') != '0'
 use_f16_pair = False
 f16_range_log = None      # a list: gemm() records (M, N, K, max |A|, max |W|) of every f16-pair launch (the format's operands must stay below 65504)
 _f16_shape = {}
@@ -210,8 +213,11 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     ldc = out.stride(0) if M > 1 else N
     n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
     x3_ok, x3_pref, nb, x3_R, x3_rows = _x3_plan(M, N, K) if sw is not None and sw.planes is not None else (False, False, 0, 0, 0)
+    # (N = 32, the level-0 KPConv contractions: a pure A stream on which the six-term bf16 strip loses to the exact-f32 kernel, 1.20 vs 1.14 ms;
+    #  the f16 pair's three terms are lighter than both -- thin_f16)
+    thin_f16 = use_f16_pair and thin_f16_gemm and N == 32 and a_stats is None and x3_ok and M >= STREAM_MIN_ROWS and f16_pair_ok(M, N, K, want_stats is not None)
     if (x3_ok and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm and (N >= 64 or a_stats is None)
-            and (force_x3_gemm or x3_pref)):
+            and (force_x3_gemm or x3_pref or thin_f16)):
         ws = _ws(nb, a.device) if nb else None
         R = x3_R if want_stats is not None else 0
         partial, s_off, n_clouds = None, None, 0
