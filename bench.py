@@ -485,7 +485,12 @@ def main():
             'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'fp32x3': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
                        'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
-                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather', 'peak_hbm_allocated_GiB': round(peak_gb, 2)},
+                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
+                       'arithmetic': {'fp32': 'float32-grade: exact operand splits on the 16-bit matrix cores (f16 pair, three MFMA terms, where the strip GEMM / attention '
+                                              'kernels serve the shape; bf16x3, six terms, elsewhere), float32 accumulation; exact-f32 MFMA in the KPConv gather',
+                                      'fp32x3': 'float32-grade: bf16x3 operand splits (six MFMA terms) everywhere, float32 accumulation',
+                                      'bf16x2': 'bf16 three-term split in the cross-encoder Linears, bf16x3 elsewhere',
+                                      'bf16': 'plain bf16 operands in the cross-encoder Linears and attention core, float32-grade elsewhere'}[dtype]},
         }
         if args.parity_pairs > 0:
             # "pose err vs ref" (BASELINE.json metric): the last timed forward's outputs against the CPU oracle, >= 2 pairs

@@ -1,4 +1,13 @@
-// C[M,N] = epilogue( A[M,K] * W[K,N] )  at float32 accuracy on the CDNA4 *bf16* matrix cores.
+// C[M,N] = epilogue( A[M,K] * W[K,N] )  at float32 accuracy on the CDNA4 16-bit matrix cores.
+//
+// TWO operand formats share the kernels of this file (FMT template parameter, n_planes of regtr_gemm_x3):
+//   bf16x3 (n_planes 3, below): x = x0 + x1 + x2 exactly, six MFMA terms, float32's full range -- the original form;
+//   f16 pair (n_planes 4, round 3): x = h0 + h1 / 2048, h0 = f16(x), h1 = f16((x - h0) * 2048): 22 mantissa bits in two planes,
+//     a w = a0 w0 + (a0 w1 + a1 w0) / 2048 + O(2^-22 |a w|) = THREE v_mfma_f32_32x32x16_f16, the two low terms in a second
+//     accumulator set scaled once in the epilogue (the scale keeps the residual plane out of f16's subnormal range).  Measured
+//     against float64 it is as accurate as the six-term form (fewer f32 accumulation roundings) at half the matrix-pipe work and
+//     two thirds of the weight bytes; operands must stay below 65504 (an overflow yields a non-finite result).  What
+//     cfg.compute_dtype 'fp32' uses; see x3_split2_f16, the FMT = 1 paths of both kernels and the f16 hand loop of k_gemm_x3d.
 //
 // gfx950 runs f32-input MFMA at 1/16 of its bf16 MFMA rate (157 TF vs 2.5 PF).  A float32 value is EXACTLY the sum of
 // three bf16 values (8 significant bits each):  x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1),

@@ -15,6 +15,7 @@ db=$(find $out/prof2 -name "*.db" | head -1); python tools/trace_forward.py $db 
 timeout 300 rocprofv3 --kernel-trace -d $out/prof3 -o trace -- python bench.py --pairs 1 --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --parity-pairs 0 > $out/prof3.log 2>&1
 db=$(find $out/prof3 -name "*.db" | head -1); python tools/trace_forward.py $db > $out/forward_trace_p1.md 2>&1; python tools/rocpd_stats.py $db > $out/kernel_stats_p1.md 2>&1; rm -rf $out/prof3; tail -1 $out/forward_trace_p1.md
 timeout 300 python tools/host_profile.py 1 > $out/host_profile_p1.txt 2>&1; head -2 $out/host_profile_p1.txt | tail -1
+timeout 600 python tools/dtype_parity.py > $out/dtype_parity.txt 2>&1; grep -c max $out/dtype_parity.txt
 # end-to-end harness: 1781 lomatch-like pairs as .pth files -> loader thread -> H2D -> forward -> gather -> est.log (second run: page cache warm)
 timeout 900 python test.py --benchmark 3DLoMatch --config regtr_amd/conf/3dmatch.yaml --logdir /tmp/e2e_logs --synthetic 1781 --overlap lomatch --materialize /tmp/e2e_data > $out/e2e.log 2>&1; grep -E "End to end" $out/e2e.log | tail -1
 timeout 600 python test.py --benchmark 3DLoMatch --config regtr_amd/conf/3dmatch.yaml --logdir /tmp/e2e_logs --synthetic 1781 --overlap lomatch --materialize /tmp/e2e_data > $out/e2e_warm.log 2>&1; grep -E "End to end" $out/e2e_warm.log | tail -1
