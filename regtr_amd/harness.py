@@ -271,4 +271,10 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
     elapsed = time.perf_counter() - t0
     if logger and rank == 0:
         logger.info(f'{n} pairs on {world} GPU(s) in {elapsed:.2f} s = {n / elapsed:.1f} pairs/s (incl. loading)')
-    return all_poses.reshape(-1, 3, 4).cpu().numpy(), all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world}
+    poses_np = all_poses.reshape(-1, 3, 4).cpu().numpy()
+    if not np.isfinite(poses_np).all():
+        bad = np.unique(np.nonzero(~np.isfinite(poses_np))[0])
+        raise RuntimeError(f'{len(bad)} of {len(poses_np)} predicted poses are not finite (first pair ids: {all_ids.cpu().numpy()[bad[:5]].tolist()}).  '
+                           "Under cfg.compute_dtype 'fp32' the tall contractions use the f16 pair operand split, whose operands must stay below 65504: "
+                           "a checkpoint with larger activations needs compute_dtype: 'fp32x3' (six-term bf16 split, float32's range) or REGTR_F16_PAIR=0")
+    return poses_np, all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world}
