@@ -119,16 +119,16 @@ class RegTR(nn.Module):
             normalize_before=cfg.pre_norm, sa_val_has_pos_emb=cfg.sa_val_has_pos_emb,
             ca_val_has_pos_emb=cfg.ca_val_has_pos_emb, attention_type=cfg.attention_type)
         encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
-        # cfg.compute_dtype (not a reference key).  Every contraction runs on the 16-bit matrix cores with EXACT operand splits and
-        # float32 accumulation.  'fp32' (default): where the row-strip GEMM serves the shape (the tall problems of a batched forward), the
-        # f16 PAIR split -- x = h0 + h1 / 2048, three f16 MFMA terms, error ~2^-22 per product, operands must stay below f16's 65504
-        # (InstanceNorm / LayerNorm outputs and their gathered sums are; a larger value gives a non-finite output, loudly) -- and
-        # elsewhere the bf16 splits: six terms (~2^-24) in the KPConv encoder, feat_proj, attention core, head and pose, the three
-        # leading terms (2^-16) in the cross-encoder's Linears.  Validated against the real reference module's outputs on all five
-        # goldens in parity mode (worst 3.3e-5, bar 1e-4; profiles/r03_dtype_parity.txt) and on the benchmarked batch (bench.py's
-        # `parity`).  'fp32x3' = six bf16 terms everywhere (full float32 operand range, no f16); 'bf16x2' = the bf16 three-term
-        # cross-encoder without the f16 pair (round-2 callers); 'bf16' = plain bf16 operands with float32 accumulation / softmax in the
-        # cross-encoder's Linears and attention core (BASELINE configs[1]; encoder, head, pose as 'fp32').
+        # cfg.compute_dtype (not a reference key).  Every dense contraction runs on the 16-bit matrix cores with EXACT operand splits and
+        # float32 accumulation.  'fp32' (default): the f16 PAIR split -- x = h0 + h1 / 2048, three f16 MFMA terms, error ~2^-22 per
+        # product, operands must stay below f16's 65504 (InstanceNorm / LayerNorm outputs and their gathered sums are: largest |A| 116 on
+        # the benchmark workload; a larger value gives a non-finite output, loudly) -- in the split GEMMs and the attention core, the
+        # six-term bf16 split (~2^-24) in the one-shot strip / block-tail kernels of the shallow levels.  Validated against the real
+        # reference module's outputs on all five goldens in parity mode (worst 2.6e-5, bar 1e-4; profiles/r03_dtype_parity.txt) and on
+        # the benchmarked batch (bench.py's `parity`: pose 8.6e-6).  'fp32x3' = six bf16 terms everywhere (full float32 operand range,
+        # no f16); 'bf16x2' = three bf16 terms in the cross-encoder's Linears without the f16 pair (round-2 callers); 'bf16' = plain
+        # bf16 operands with float32 accumulation / softmax in the cross-encoder's Linears and attention core (BASELINE configs[1];
+        # encoder, head, pose as 'fp32').
         dt = cfg.get('compute_dtype', 'fp32')
         if dt not in ('fp32', 'fp32x3', 'bf16', 'bf16x2'):
             raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, fp32x3, bf16x2 or bf16')
