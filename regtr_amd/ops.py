@@ -416,15 +416,22 @@ def add(a, b):
     return out
 
 
+_posemb_tables = {}
+
+
 def posemb_sine(xyz, d_model, scale=1.0, temperature=10000):
     """PositionEmbeddingCoordsSine.forward (position_embedding.py:29-50).  The 84-entry frequency table is
     init-time constant data computed exactly the way the reference computes it (float32 pow)."""
     n_dim = 3
     npf = d_model // n_dim // 2 * 2
-    dim_t = torch.arange(npf, dtype=torch.float32)
-    dim_t = (temperature ** (2 * torch.div(dim_t, 2, rounding_mode='trunc') / npf)).to(xyz.device)
+    key = (npf, temperature, float(scale), xyz.device)
+    ent = _posemb_tables.get(key)
+    if ent is None:          # (once per configuration and device: building these per forward cost a one-pair forward 0.2 ms of host time)
+        dim_t = torch.arange(npf, dtype=torch.float32)
+        dim_t = (temperature ** (2 * torch.div(dim_t, 2, rounding_mode='trunc') / npf)).to(xyz.device)
+        ent = _posemb_tables[key] = (dim_t, torch.tensor(scale * 2 * math.pi, dtype=torch.float32).item())
+    dim_t, scale32 = ent
     pe = torch.empty((xyz.shape[0], d_model), dtype=torch.float32, device=xyz.device)
-    scale32 = torch.tensor(scale * 2 * math.pi, dtype=torch.float32).item()
     check(_lib.lib().regtr_posemb_sine(ptr(xyz), xyz.shape[0], npf, d_model, scale32, ptr(dim_t), ptr(pe), stream()),
           'regtr_posemb_sine')
     return pe
