@@ -53,7 +53,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 7
+#define REGTR_ABI_VERSION 8
 int regtr_abi_version(void);
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
@@ -138,6 +138,14 @@ int regtr_kdtree_radius_query(const float* q_xyz, const int* q_seg_off, int nq_c
  * x' = x, or LeakyReLU_slope(InstanceNorm(x)) when stats [n_seg,C,2] + seg_off [n_seg+1] are given (fused UnaryBlock tail). */
 int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
                           float* flag, void* stream);
+
+/* The deep-level gather on the f16 matrix pipe (Cin a multiple of 64, H <= 40): feature rows as f16 pair planes [n][2][Cin]
+ * (regtr_f16_pair_planes of the normalised float32 features: x = h0 + h1 / 2048, the same 4 bytes per value), staged in LDS and read back
+ * transposed (ds_read_b64_tr_b16) as v_mfma_f32_16x16x32_f16 operands; float32-grade like regtr_kpconv_gather, operands below 65504. */
+int regtr_f16_pair_planes(const float* x, int n, int C, void* planes, void* stream);
+int regtr_kpconv_gather_f16_supported(int Cin, int H, int KP);
+int regtr_kpconv_gather_f16(const float* q_xyz, int nq, int ns, const int* nbr, int H, const void* x_planes, int Cin, const float* s_xyzf,
+                            const float* kernel_points, int KP, float extent, float* wf, float* num, void* stream);
 
 /* 1 when regtr_kpconv_gather derives the positivity flags from the feature rows it gathers anyway (Cin == 1 or a
  * multiple of 32 with H <= 64, 16-byte aligned x / wf / x_stats): `flag` may then be NULL and regtr_rowsum_positive skipped. */

@@ -20,7 +20,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 7          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 8          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -39,6 +39,9 @@ SIGNATURES = {
     'regtr_nearest_in_radius': (_I, [_P, _P, _I, _P, _I, _I, _c.c_double, _F, _P, _Z, _P, _P]),
     'regtr_overlap_avgpool': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
+    'regtr_f16_pair_planes': (_I, [_P, _I, _I, _P, _P]),
+    'regtr_kpconv_gather_f16_supported': (_I, [_I, _I, _I]),
+    'regtr_kpconv_gather_f16': (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
     'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _I, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),

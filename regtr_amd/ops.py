@@ -487,10 +487,18 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     if rec is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
+    # deep levels, packed records, final features: the gather on the f16 matrix pipe (feature rows as f16 pair planes)
+    if (use_f16_gather and xyzf is not None and x_stats is None and nq >= F16_GATHER_MIN_ROWS and ns * Cin < (1 << 29)
+            and L.regtr_kpconv_gather_f16_supported(Cin, H, KP)):
+        planes = torch.empty((ns, Cin), dtype=torch.float32, device=dev)         # [ns][2][Cin] f16 = 4 bytes per value
+        check(L.regtr_f16_pair_planes(ptr(x), ns, Cin, ptr(planes), stream()), 'regtr_f16_pair_planes')
+        check(L.regtr_kpconv_gather_f16(ptr(q_xyz), nq, ns, iptr(nbr), H, ptr(planes), Cin, ptr(xyzf), ptr(kernel_points), KP,
+                                        float(extent), ptr(wf), ptr(num), stream()), 'regtr_kpconv_gather_f16')
+    else:
+      check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
                                 iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), 0, ptr(num), stream()),
-          'regtr_kpconv_gather')
+            'regtr_kpconv_gather')
     if rec is not None:
         e1.record()
     res = gemm(wf, w_flat, row_div=num, want_stats=want_stats)       # (out, stats) when want_stats is given
@@ -499,6 +507,10 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         rec.append((e0, e1, e2, nq, H, Cin, (res[0] if want_stats is not None else res).shape[1]))
     return res
 
+
+# the deep-level gather (Cin a multiple of 64) on the f16 matrix pipe (csrc/kpconv.hip k_kpconv_gather_f16); A-B runs / tests
+use_f16_gather = os.environ.get('REGTR_F16_GATHER', '0') != '0'
+F16_GATHER_MIN_ROWS = 1
 
 # bench.py sets this to a list to time every KPConv gather launch (HIP events on the launch stream = torch's current one)
 gather_records = None
