@@ -70,7 +70,16 @@ int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int
  * the iteration order of the libstdc++ std::unordered_map<size_t, .> it fills in input order (grid_subsampling.cpp:48,58-59,85)
  * -- the parity mode (cfg.kpconv_ref_row_order); one thread per cloud replays the container (csrc/ref_order.h). */
 size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_order);
-int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order,
+/* key_mode: which of the reference's two voxel rules.
+ *   0  floor((p - origin) / dl), origin = floor(min corner * (1 / dl)) * dl, linear size_t key -- the CPU Preprocessor's
+ *      cpp_subsampling (grid_subsampling.cpp:25-31,53-56); bit-exact against the unmodified reference C++;
+ *   1  floor(p / dl), no origin shift, float32 IEEE division -- PreprocessorGPU, the class the reference model instantiates
+ *      (regtr.py:29; kpconv.py:213-240: MinkowskiEngine quantisation of points / sampleDl);
+ *   2  floor(p * (1 / dl)), reciprocal rounded to float32 -- the same rule as torch's CUDA division by a host scalar evaluates it.
+ * 0 and 1 give DIFFERENT voxel sets wherever points sit on voxel faces (3DMatch fragments lie on a lattice: red-kitchen pair
+ * 9 977 vs 10 088 level-1 points).  Barycentre arithmetic and the first-appearance row order are the same for every mode
+ * (MinkowskiEngine's own output order and summation order are unspecified).  row_order 1 requires key_mode 0. */
+int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order, int key_mode,
                                  float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
 
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds);

@@ -47,7 +47,8 @@ def canonical_meta(pts_list, cfg):
         K = limits[l]
         conv = table(pts, pts, lens, lens, K)                                              # :349-351
         if l + 1 < n_levels:
-            sub, sl = native.grid_subsample(pts, lens, 2 * r / cfg['conv_radius'])         # :363-366
+            sub, sl = native.grid_subsample(pts, lens, 2 * r / cfg['conv_radius'],             # :363-366
+                                            key_mode=native.VOXEL_KEY_MODES[cfg.get('kpconv_voxel_key', 'origin')])
             pool = table(sub, pts, sl, lens, K)                                            # :376
         else:
             sub, sl, pool = np.zeros((0, 3), np.float32), np.zeros(0, np.int32), np.zeros((0, 1), np.int32)

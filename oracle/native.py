@@ -45,6 +45,7 @@ def oracle_lib():
             build(ref=False)
         _oracle = ctypes.CDLL(_ORACLE_SO)
         _oracle.oracle_grid_subsample.restype = ctypes.c_int
+        _oracle.oracle_grid_subsample_keyed.restype = ctypes.c_int
     return _oracle
 
 
@@ -64,16 +65,20 @@ def ref_lib():
 
 
 # ----------------------------------------------------------------------------- restatement
-def grid_subsample(points, lens, dl, return_keys=False, ref_order=False):
+VOXEL_KEY_MODES = {'origin': 0, 'floor': 1, 'floor_rcp': 2}
+
+
+def grid_subsample(points, lens, dl, return_keys=False, ref_order=False, key_mode=0):
     """-> (pts (M,3) f32, lens (B,) i32[, keys (M,) u64]).  Rows in canonical first-appearance order, or in
-    the reference's libstdc++ unordered_map iteration order when ref_order=True."""
+    the reference's libstdc++ unordered_map iteration order when ref_order=True.  key_mode 0: the CPU op's voxel rule;
+    1 / 2: PreprocessorGPU's floor(p / dl) (regtr_oracle.cpp: oracle_grid_subsample_keyed)."""
     points, lens = _f32(points), _i32(lens)
     n, nb = points.shape[0], lens.shape[0]
     out = np.empty((max(n, 1), 3), np.float32)
     out_lens = np.empty(nb, np.int32)
     keys = np.empty(max(n, 1), np.uint64)
-    m = oracle_lib().oracle_grid_subsample(
-        points.ctypes.data_as(_f32p), n, lens.ctypes.data_as(_i32p), nb, ctypes.c_float(dl), int(ref_order),
+    m = oracle_lib().oracle_grid_subsample_keyed(
+        points.ctypes.data_as(_f32p), n, lens.ctypes.data_as(_i32p), nb, ctypes.c_float(dl), int(ref_order), int(key_mode),
         out.ctypes.data_as(_f32p), out_lens.ctypes.data_as(_i32p),
         keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
     if return_keys:

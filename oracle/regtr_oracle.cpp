@@ -46,8 +46,14 @@ extern "C" {
 // order = 0: canonical (first appearance).  order = 1: the reference's exact row order, obtained the way
 // the reference obtains it -- iterating a libstdc++ std::unordered_map<size_t, .> filled by emplace in
 // input order (grid_subsampling.cpp:48,58-59,85); only meaningful with the same libstdc++.
-int oracle_grid_subsample(const float* points, int n, const int* lens, int nb, float dl, int order,
-                          float* out_pts, int* out_lens, uint64_t* out_keys)
+// key_mode 0: the CPU op's rule above.  key_mode 1 / 2: the reference's PreprocessorGPU (models/backbone_kpconv/kpconv.py:213-240),
+// which hands `points / sampleDl` to MinkowskiEngine's sparse quantisation: integer coordinates floor(p / dl), no origin shift,
+// unweighted average of the members.  1 = float32 IEEE division (torch CPU / numpy), 2 = p * (1.0f / dl) (torch's CUDA kernel for a
+// division by a host scalar multiplies by the float32 reciprocal).  PARITY UNPINNED for 1 / 2: MinkowskiEngine 0.5.4 is absent (its
+// output order and summation order are unspecified anyway, kpconv.py:216-217); what is restated is the voxel membership rule, which
+// the call site fixes, with the barycentre arithmetic and first-appearance order of mode 0.
+int oracle_grid_subsample_keyed(const float* points, int n, const int* lens, int nb, float dl, int order, int key_mode,
+                                float* out_pts, int* out_lens, uint64_t* out_keys)
 {
     int base = 0, m = 0;
     for (int b = 0; b < nb; b++) {
@@ -75,7 +81,17 @@ int oracle_grid_subsample(const float* points, int n, const int* lens, int nb, f
             const size_t iX = (size_t)std::floor((x - org[0]) / dl);       // :53-55
             const size_t iY = (size_t)std::floor((y - org[1]) / dl);
             const size_t iZ = (size_t)std::floor((z - org[2]) / dl);
-            const uint64_t key = iX + NX * iY + NX * NY * iZ;              // :56
+            uint64_t key = iX + NX * iY + NX * NY * iZ;                    // :56
+            if (key_mode != 0) {                                           // kpconv.py:232-233: floor(p / dl), three integers
+                const float inv = 1.0f / dl;
+                const float c[3] = {x, y, z};
+                key = 0;
+                for (int a = 2; a >= 0; a--) {
+                    float f = std::floor(key_mode == 1 ? c[a] / dl : c[a] * inv);
+                    f = std::min(std::max(f, -1048576.f), 1048575.f);
+                    key = (key << 21) | (uint64_t)((int)f + 1048576);
+                }
+            }
             auto it = slot.find(key);
             int s;
             if (it == slot.end()) {
@@ -102,6 +118,12 @@ int oracle_grid_subsample(const float* points, int n, const int* lens, int nb, f
         base += nbp;
     }
     return m;
+}
+
+int oracle_grid_subsample(const float* points, int n, const int* lens, int nb, float dl, int order,
+                          float* out_pts, int* out_lens, uint64_t* out_keys)
+{
+    return oracle_grid_subsample_keyed(points, n, lens, nb, dl, order, 0, out_pts, out_lens, out_keys);
 }
 
 // Brute-force fixed-radius neighbours restricted to the same cloud.

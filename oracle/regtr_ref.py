@@ -64,7 +64,8 @@ def preprocess(pts_list, cfg, use_ref_cpp=False):
             if use_ref_cpp:
                 pool_p, pool_b = native.ref_subsample_batch(pts, lens, dl)  # :366
             else:
-                pool_p, pool_b = native.grid_subsample(pts, lens, dl)
+                # cfg.kpconv_voxel_key: 'origin' = the CPU op (kpconv.py:170-181), 'floor' / 'floor_rcp' = PreprocessorGPU (kpconv.py:213-240)
+                pool_p, pool_b = native.grid_subsample(pts, lens, dl, key_mode=native.VOXEL_KEY_MODES[cfg.get('kpconv_voxel_key', 'origin')])
             pool_i = radius(pool_p, pts, pool_b, lens, r_normal, K)         # :376
             # up_i (kpconv.py:380) is never read by RegTR (no decoder, kpconv.py:93-94): skipped.
         else:

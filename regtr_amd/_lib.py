@@ -27,7 +27,7 @@ SIGNATURES = {
     'regtr_grid_subsample_ws_bytes': (_Z, [_I, _I]),
     'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'regtr_grid_subsample_ordered_ws_bytes': (_Z, [_I, _I, _I]),
-    'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     'regtr_kdtree_ws_bytes': (_Z, [_I, _I]),
     'regtr_kdtree_query_scratch_bytes': (_Z, [_I]),
     'regtr_kdtree_build': (_I, [_P, _P, _I, _I, _P, _Z, _P]),

@@ -230,9 +230,19 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, con
     bbox_flush(cur, mn, mx, bbox);
 }
 
-// voxel key of every point, exactly as grid_subsampling.cpp:25-31,53-56 computes it (float32, no contraction)
+// voxel key of every point.  key_mode 0: exactly as grid_subsampling.cpp:25-31,53-56 computes it (float32, no contraction) -- the
+// reference's CPU Preprocessor.  key_mode 1 / 2: the reference's PreprocessorGPU (kpconv.py:213-240: MinkowskiEngine quantisation of
+// points / sampleDl, i.e. integer coordinates floor(p / dl) with NO origin shift): 1 = IEEE float32 division (torch on the CPU, numpy),
+// 2 = p * (1 / dl) with the reciprocal rounded to float32 (what torch's CUDA division by a host scalar evaluates).  The three integer
+// coordinates are packed 21 bits each (|floor(p / dl)| < 2^20: 52 km at dl = 5 cm; beyond that coordinates saturate).
+__device__ __forceinline__ uint64_t rg_pack_coord(float f)
+{
+    const float c = fminf(fmaxf(floorf(f), -1048576.f), 1048575.f);
+    return (uint64_t)((int)c + 1048576);
+}
+
 __global__ void __launch_bounds__(256) k_voxel_keys(const float* __restrict__ xyz, const int* __restrict__ seg_off, int n_clouds,
-                                                    const int* __restrict__ pcid, const int* __restrict__ bbox, float dl,
+                                                    const int* __restrict__ pcid, const int* __restrict__ bbox, float dl, int key_mode,
                                                     uint64_t* __restrict__ pkey)
 {
     const int n = seg_off[n_clouds];
@@ -242,10 +252,18 @@ __global__ void __launch_bounds__(256) k_voxel_keys(const float* __restrict__ xy
     const float inv = __fdiv_rn(1.0f, dl);
     float org[3], mx[3], p[3];
 #pragma unroll
+    for (int a = 0; a < 3; a++) p[a] = xyz[3 * (size_t)i + a];
+    if (key_mode != 0) {
+        uint64_t c[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) c[a] = rg_pack_coord(key_mode == 1 ? __fdiv_rn(p[a], dl) : __fmul_rn(p[a], inv));
+        pkey[i] = (c[2] << 42) | (c[1] << 21) | c[0];
+        return;
+    }
+#pragma unroll
     for (int a = 0; a < 3; a++) {
         org[a] = __fmul_rn(floorf(__fmul_rn(rg_ord2f(bbox[cid * 6 + a]), inv)), dl);
         mx[a] = rg_ord2f(bbox[cid * 6 + 3 + a]);
-        p[a] = xyz[3 * (size_t)i + a];
     }
     // (size_t)floor(float): negative values wrap exactly like the x86-64 cvttss2si path the reference takes
     const uint64_t NX = (uint64_t)(int64_t)floorf(__fdiv_rn(__fsub_rn(mx[0], org[0]), dl)) + 1;
@@ -856,10 +874,11 @@ size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_or
 }
 size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds) { return regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, 0); }
 
-int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order,
+int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order, int key_mode,
                                  float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
 {
-    if (!xyz || !seg_off || !out_xyz || !out_seg_off || n_clouds < 1 || n_cap < 0 || !(dl > 0.f) || row_order < 0 || row_order > 1)
+    if (!xyz || !seg_off || !out_xyz || !out_seg_off || n_clouds < 1 || n_cap < 0 || !(dl > 0.f) || row_order < 0 || row_order > 1
+        || key_mode < 0 || key_mode > 2 || (row_order == 1 && key_mode != 0))      // the container order belongs to the CPU op's keys
         return RG_ERR_ARG;
     if (ws_bytes < regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, row_order)) return RG_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -878,7 +897,7 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
     k_clear_tables<<<rg_cdiv(T, 256), 256, 0, st>>>(n_ptr, rep, cnt, fill, first);
     k_init_bbox<<<rg_cdiv(n_clouds * 6, 256), 256, 0, st>>>(bbox, n_clouds);
     k_bbox<<<rg_cdiv(n_cap, 256 * BBOX_ITEMS), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
-    k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, pkey);
+    k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, key_mode, pkey);
     k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, slot_of, first, cnt);
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);
     scan_u64(scan_in, n_ptr, n_cap, bsum, scan_out, st);
@@ -896,7 +915,7 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
 int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
                          int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
 {
-    return regtr_grid_subsample_ordered(xyz, seg_off, n_clouds, n_cap, dl, 0, out_xyz, out_seg_off, ws, ws_bytes, stream);
+    return regtr_grid_subsample_ordered(xyz, seg_off, n_clouds, n_cap, dl, 0, 0, out_xyz, out_seg_off, ws, ws_bytes, stream);
 }
 
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds)

@@ -5,13 +5,13 @@ Host-side mirror of /root/reference/src/models/backbone_kpconv/kpconv.py (Prepro
 :533-567, KPConv :175-414): same constructor arguments, same parameter names, same `kpconv_meta` dictionary.  All
 arithmetic is in libregtr_hip.so.
 
-Semantics are those of the reference's CPU ops (cpp_wrappers): voxel key floor((p - origin) / dl), neighbours
-distance-sorted then truncated to neighborhood_limits.  Documented differences, none of which changes a downstream
-value beyond float rounding and ties: neighbour tables always have K = neighborhood_limits[l] columns like the reference's
-GPU path (kpconv.py:276-283; its CPU path emits min(max_count, K), kpconv.py:255-258 -- the extra columns are shadow
-indices), exact-distance ties are ordered by support index, subsampled rows are in first-appearance order, index tensors
-are int32 unless cfg.kpconv_meta_int64 is set, and the unused `upsamples` tables (kpconv.py:503-504; RegTR has no
-decoder) are left empty.
+Default semantics are those of the reference's CPU ops (cpp_wrappers; the only path whose outputs can be generated and pinned in a
+container without MinkowskiEngine / pytorch3d): voxel key floor((p - origin) / dl), neighbours distance-sorted then truncated to
+neighborhood_limits.  Documented differences, none of which changes a downstream value beyond float rounding and ties: neighbour
+tables always have K = neighborhood_limits[l] columns like the reference's GPU path (kpconv.py:276-283; its CPU path emits
+min(max_count, K), kpconv.py:255-258 -- the extra columns are shadow indices), exact-distance ties are ordered by support index,
+subsampled rows are in first-appearance order, index tensors are int32 unless cfg.kpconv_meta_int64 is set, and the unused
+`upsamples` tables (kpconv.py:503-504; RegTR has no decoder) are left empty.
 
 cfg.kpconv_ref_row_order = True selects the PARITY MODE: every implementation-defined choice of the reference's CPU
 ops is reproduced on the GPU -- subsampled rows in libstdc++ unordered_map iteration order, neighbour rows in nanoflann
@@ -20,14 +20,21 @@ min(max_count, K) wide (a full row then has no zero shadow row in max_pool) -- s
 `Preprocessor`'s output element for element and the network outputs can be compared with the reference's own at 1e-4
 (tests/test_gpu_model.py).  It costs extra host synchronisations and serial kernels; the default mode stays the fast one.
 
-cfg.kpconv_neighbor_order = 'index' selects the neighbour SETS of the reference's PreprocessorGPU (the class its model actually
-instantiates, regtr.py:29): pytorch3d ball_query keeps the FIRST K supports of a ball in index order (kpconv.py:261-288), where the
-CPU Preprocessor keeps the K nearest.  The two differ only on rows whose ball holds more than neighborhood_limits supports (15 % of
-level-0 rows on 3DMatch).  Same speed as the default; rows come out ascending by support index.  The subsampling is the same in
-both reference paths up to float rounding on voxel boundaries (grid origin = a multiple of dl either way: grid_subsampling.cpp:25-31
-vs floor(p / dl), kpconv.py:232-233) and the row order of MinkowskiEngine's quantisation is unspecified, so it is left as is.
-pytorch3d / MinkowskiEngine cannot be installed here: this mode is pinned to a restatement of ball_query's documented behaviour
-(oracle/regtr_ref.py: ball_query_first_k), not to the libraries themselves.
+The reference MODEL instantiates PreprocessorGPU (regtr.py:29), whose two ops follow different rules from the CPU ones -- both are
+selectable, together they are that class's semantics (test.py --preprocessor gpu sets both):
+ * cfg.kpconv_neighbor_order = 'index': pytorch3d ball_query keeps the FIRST K supports of a ball in index order
+   (kpconv.py:261-288), where the CPU Preprocessor keeps the K nearest.  The two differ on rows whose ball holds more than
+   neighborhood_limits supports (15 % of level-0 rows on 3DMatch).  Rows come out ascending by support index.
+ * cfg.kpconv_voxel_key = 'floor': MinkowskiEngine quantises points / sampleDl, i.e. the voxel of p is floor(p / dl) with NO origin
+   shift (kpconv.py:230-239), where the CPU op takes floor((p - origin) / dl) with origin = floor(min corner / dl) * dl
+   (grid_subsampling.cpp:25-31,53-55).  These are DIFFERENT voxel sets on real data: 3DMatch fragments sit on a lattice that puts
+   whole planes of points exactly on voxel faces, where (p - origin) / dl and p / dl round to different sides -- the red-kitchen
+   pair subsamples to 9 977 level-1 points under the CPU rule and 10 088 under this one.  'floor_rcp' evaluates p * (1 / dl) with a
+   float32 reciprocal, which is what torch's CUDA kernel computes for a division by a host scalar (10 037 points on the same pair).
+Both run at the default mode's speed.  pytorch3d / MinkowskiEngine cannot be installed here, so these modes are held to
+restatements of the call sites' documented rules (oracle/regtr_ref.py: ball_query_first_k; oracle/regtr_oracle.cpp:
+oracle_grid_subsample_keyed) -- parity UNPINNED for them; MinkowskiEngine's row and summation orders are unspecified in the reference
+itself (kpconv.py:216-217), first-appearance order and in-order float32 sums are used.
 """
 from typing import List
 
@@ -91,8 +98,12 @@ class Preprocessor(nn.Module):
         # parity mode: the reference CPU ops' implementation-defined row orders and table widths (see module docstring)
         ref_order = bool(cfg.get('kpconv_ref_row_order', False))
         nb_order = {'nearest': 0, 'index': 1}[cfg.get('kpconv_neighbor_order', 'nearest')]
-        if ref_order and nb_order:
-            raise ValueError('kpconv_ref_row_order reproduces the CPU Preprocessor; kpconv_neighbor_order = index is the GPU one')
+        key_name = cfg.get('kpconv_voxel_key', 'origin')
+        if key_name not in ops.VOXEL_KEY_MODES:
+            raise ValueError(f'kpconv_voxel_key {key_name!r}: choose origin (CPU Preprocessor), floor or floor_rcp (PreprocessorGPU)')
+        key_mode = ops.VOXEL_KEY_MODES[key_name]
+        if ref_order and (nb_order or key_mode):
+            raise ValueError('kpconv_ref_row_order reproduces the CPU Preprocessor; kpconv_neighbor_order = index / kpconv_voxel_key = floor are the GPU one')
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
@@ -120,7 +131,7 @@ class Preprocessor(nn.Module):
                 if layer == 0 and level0_event is not None:
                     level0_event.record()
                 if strided:
-                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl)          # :366
+                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, key_mode=key_mode)          # :366 / :213-240
                     pool_i = grid.query(pool_p, pool_seg, cap, K, order=nb_order)        # :376
             else:
                 tree = ops.KdTree(points, seg, cap)

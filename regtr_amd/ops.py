@@ -16,17 +16,21 @@ def _ws(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ preprocessing
-def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0):
+VOXEL_KEY_MODES = {'origin': 0, 'floor': 1, 'floor_rcp': 2}
+
+
+def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0, key_mode=0):
     """xyz (n_cap,3) f32, seg_off (B+1,) i32 [device] -> (out_xyz (n_cap,3) [first out_seg_off[-1] rows live],
     out_seg_off (B+1,) i32 [device]).  Row order: clouds stacked; voxels of a cloud by first appearance (row_order 0) or in
-    the reference's libstdc++ unordered_map iteration order (row_order 1, parity mode)."""
+    the reference's libstdc++ unordered_map iteration order (row_order 1, parity mode).  key_mode: 0 the CPU op's voxel rule
+    floor((p - origin) / dl), 1 PreprocessorGPU's floor(p / dl), 2 floor(p * (1 / dl)) (include/regtr_hip.h)."""
     L = _lib.lib()
     n_clouds = seg_off.numel() - 1
     out = torch.empty((max(n_cap, 1), 3), dtype=torch.float32, device=xyz.device)
     out_off = torch.empty(n_clouds + 1, dtype=torch.int32, device=xyz.device)
     nb = L.regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, int(row_order))
     ws = _ws(nb, xyz.device)
-    check(L.regtr_grid_subsample_ordered(ptr(xyz), iptr(seg_off), n_clouds, n_cap, float(dl), int(row_order), ptr(out),
+    check(L.regtr_grid_subsample_ordered(ptr(xyz), iptr(seg_off), n_clouds, n_cap, float(dl), int(row_order), int(key_mode), ptr(out),
                                          iptr(out_off), bptr(ws), nb, stream()), 'regtr_grid_subsample_ordered')
     return out, out_off
 

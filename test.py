@@ -8,7 +8,8 @@ Runs the MI355X-native RegTR inference path over the benchmark's pairs and write
 (3DMatch / 3DLoMatch) or `<log>/pred_transforms.npy` (ModelNet / ModelLoNet) in the reference's formats
 (models/generic_reg_model.py:194-195, 260-281), which the reference's evaluation scripts read unchanged.
 Inference only: no loss, no tensorboard.  Extra flags: --batch (pairs per forward), --data_root, --synthetic N
-(N deterministic synthetic pairs instead of the dataset files), --max_pairs, --neighbor_order (nearest | index: which reference preprocessor's neighbour rule), --benchmark_dir (gt.log / gt.info folder: the
+(N deterministic synthetic pairs instead of the dataset files), --max_pairs, --preprocessor (cpu | gpu: which reference preprocessor's semantics;
+--neighbor_order / --voxel_key set its two rules one by one), --benchmark_dir (gt.log / gt.info folder: the
 Predator registration-recall table of benchmark/benchmark_predator.py is then printed, computed in process).
 """
 import argparse
@@ -48,6 +49,12 @@ parser.add_argument('--max_pairs', type=int, default=None)
 parser.add_argument('--neighbor_order', choices=('nearest', 'index'), default=None,
                     help='neighbour selection rule: nearest = the reference CPU Preprocessor (default), index = its PreprocessorGPU '
                          '(pytorch3d ball_query: first K supports of a ball by index); overrides cfg.kpconv_neighbor_order')
+parser.add_argument('--voxel_key', choices=('origin', 'floor', 'floor_rcp'), default=None,
+                    help='voxel rule of the grid subsampling: origin = the reference CPU Preprocessor (default), floor = its PreprocessorGPU '
+                         '(MinkowskiEngine: floor(p / dl), no origin shift); overrides cfg.kpconv_voxel_key')
+parser.add_argument('--preprocessor', choices=('cpu', 'gpu'), default=None,
+                    help="which reference preprocessor's semantics: cpu = Preprocessor (nearest + origin; default, pinned), "
+                         'gpu = PreprocessorGPU, the class the reference model instantiates (index + floor)')
 parser.add_argument('--benchmark_dir', type=str, default=os.path.join('datasets', '3dmatch', 'benchmarks'),
                     help='folder with <benchmark>/<scene>/gt.log, gt.info for the registration-recall table')
 
@@ -98,8 +105,13 @@ def main():
     from regtr_amd import RegTR, load_config
     from regtr_amd import harness
     cfg = load_config(opt.config)
+    if opt.preprocessor:
+        cfg.update({'kpconv_neighbor_order': 'index' if opt.preprocessor == 'gpu' else 'nearest',
+                    'kpconv_voxel_key': 'floor' if opt.preprocessor == 'gpu' else 'origin'})
     if opt.neighbor_order:
         cfg.update({'kpconv_neighbor_order': opt.neighbor_order})
+    if opt.voxel_key:
+        cfg.update({'kpconv_voxel_key': opt.voxel_key})
     if cfg.dataset == '3dmatch':
         assert opt.benchmark in ['3DMatch', '3DLoMatch'], "Benchmark for 3dmatch dataset must be one of ['3DMatch', '3DLoMatch']"
         cfg.benchmark = opt.benchmark

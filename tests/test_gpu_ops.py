@@ -334,6 +334,30 @@ def test_radius_first_k_by_index_vs_restatement():
     assert (np.sort(near, 1) != np.sort(got_pool, 1)).any()
 
 
+@pytest.mark.parametrize('mode', [1, 2])
+def test_grid_subsample_floor_keys_vs_restatement(mode):
+    """key_mode 1 / 2 (the reference PreprocessorGPU's voxel rule floor(p / dl), kpconv.py:213-240) against the restatement: lattice
+    clouds with points exactly on voxel faces, negative coordinates, an empty and a one-point cloud; bit-exact barycentres in
+    first-appearance order, and a voxel set that differs from the CPU rule's (key_mode 0)."""
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    clouds = [synth_cloud(rng, 6000, lattice=0.00625) - 1.3, np.zeros((0, 3), np.float32), synth_cloud(rng, 1, lattice=0.05),
+              (rng.integers(-40, 40, (5000, 3)) * 0.0125).astype(np.float32)]
+    pts = np.concatenate(clouds).astype(np.float32); lens = np.array([len(c) for c in clouds], np.int32)
+    dl = 0.05
+    out, out_seg = ops.grid_subsample(to_dev(pts), seg_of(lens), len(pts), dl, key_mode=mode)
+    oseg = out_seg.cpu().numpy()
+    ref_p, ref_l = native.grid_subsample(pts, lens, dl, key_mode=mode)
+    assert np.array_equal(np.diff(oseg), ref_l)
+    assert np.array_equal(out[:oseg[-1]].cpu().numpy(), ref_p)
+    cpu_rule = native.grid_subsample(pts, lens, dl, key_mode=0)[1]
+    assert not np.array_equal(cpu_rule, ref_l)                              # face points fall the other way without the origin shift
+    # membership: every input point's floor(p / dl) cell holds exactly one output barycentre of its cloud
+    k = np.floor(pts / np.float32(dl) if mode == 1 else pts * (np.float32(1) / np.float32(dl))).astype(np.int64)
+    cid = np.repeat(np.arange(len(lens)), lens)
+    assert len(np.unique(np.concatenate([cid[:, None], k], 1), axis=0)) == int(ref_l.sum())
+
+
 # ------------------------------------------------------------------------------------------------ encoder kernels
 @pytest.mark.parametrize('Cin,Cout,H', [(1, 64, 40), (32, 32, 40), (64, 64, 40), (128, 128, 50), (256, 256, 40),
                                         (16, 64, 40), (48, 32, 40), (20, 12, 33)])      # last three: general LDS-tile gather + flag pass
