@@ -9,6 +9,11 @@ Cases
   modelnet_attn_head : the ModelNet pair with direct_regress_coor: False (attention CorrespondenceDecoder)
   3dmatch_crop_b2 : TWO ragged red-kitchen crop pairs in ONE forward (B = 2): the reference's padded (N_max, B, D) tokens +
                     key_padding_mask path (regtr.py:147-172, transformers.py:197-226) against the packed-token path here
+  3dmatch_hotel   : demo.py example 1, sun3d-hotel_umd-maryland_hotel3 cloud_bin_8 / 15 (demo.py:31-34)
+  3dmatch_home_at : demo.py example 2, sun3d-home_at-home_at_scan1_2013_jan_1 cloud_bin_38 / 41 (demo.py:35-38): the dense one --
+                    22.7 % of its level-0 balls hold more than K = 40 supports (2.5x the kitchen's truncation / tie pressure)
+  modelnet_630    : demo.py example 4, modelnet_test_630_{0,1}.ply (demo.py:44-47)
+  (with modelnet_demo = example 3 and 3dmatch_kitchen = example 0 these are all five pairs the reference ships)
 Each file holds the float32 inputs, the reference module's outputs (reference row order) with
 weights = oracle.seeded_weights.seeded_state_dict(cfg, seed=0), and the reference C++'s
 per-level points / stack lengths.  `native_*` files hold raw outputs of the reference C++ ops.
@@ -147,6 +152,17 @@ def main():
     if os.environ.get('GOLDEN_ONLY') in (None, 'batch'):
         run_batch_case('3dmatch_crop_b2', '3dmatch', [(c0, c5), (crop(k0, 0.6), crop(k5, 0.7))])
         if os.environ.get('GOLDEN_ONLY') == 'batch':
+            return
+    if os.environ.get('GOLDEN_ONLY') in (None, 'demo'):
+        # the reference's remaining shipped pairs (demo.py:26-49, examples 1, 2, 4)
+        ind = os.path.join(DATA, 'indoor', 'test')
+        run_case('3dmatch_hotel', '3dmatch', load_pth(os.path.join(ind, 'sun3d-hotel_umd-maryland_hotel3/cloud_bin_8.pth')),
+                 load_pth(os.path.join(ind, 'sun3d-hotel_umd-maryland_hotel3/cloud_bin_15.pth')))
+        run_case('3dmatch_home_at', '3dmatch', load_pth(os.path.join(ind, 'sun3d-home_at-home_at_scan1_2013_jan_1/cloud_bin_38.pth')),
+                 load_pth(os.path.join(ind, 'sun3d-home_at-home_at_scan1_2013_jan_1/cloud_bin_41.pth')))
+        run_case('modelnet_630', 'modelnet', read_ply_xyz(os.path.join(DATA, 'modelnet_demo_data', 'modelnet_test_630_0.ply')),
+                 read_ply_xyz(os.path.join(DATA, 'modelnet_demo_data', 'modelnet_test_630_1.ply')))
+        if os.environ.get('GOLDEN_ONLY') == 'demo':
             return
     run_case('modelnet_demo', 'modelnet', m0, m1)
     run_case('3dmatch_crop', '3dmatch', c0, c5, with_feats=True)

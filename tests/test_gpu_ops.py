@@ -191,9 +191,11 @@ def test_preprocess_native_fixture(case):
         o += n
 
 
-def test_preprocess_full_pyramid_kitchen():
-    """3DMatch-sized real pair: every level's points and both neighbour tables bit exact vs the oracle."""
-    g = gold('3dmatch_kitchen')
+@pytest.mark.parametrize('case', ['3dmatch_kitchen', '3dmatch_home_at', '3dmatch_hotel'])
+def test_preprocess_full_pyramid_kitchen(case):
+    """3DMatch-sized real pairs (the three the reference ships; home_at: 22.7 % of level-0 balls overflow K = 40): every level's points
+    and both neighbour tables bit exact vs the oracle."""
+    g = gold(case)
     pts = np.concatenate([g['src'], g['tgt']]); lens = np.array([len(g['src']), len(g['tgt'])], np.int32)
     dl, r = 0.05, 0.0625
     for level in range(4):

@@ -67,6 +67,7 @@ POSTNORM = {'pre_norm': False, 'sa_val_has_pos_emb': False, 'ca_val_has_pos_emb'
 
 
 @pytest.mark.parametrize('case,cfgn,overrides', [('modelnet_demo', 'modelnet', {}), ('3dmatch_crop', '3dmatch', {}),
+                                                 ('modelnet_630', 'modelnet', {}), ('3dmatch_home_at', '3dmatch', {}),
                                                  ('modelnet_postnorm', 'modelnet', POSTNORM),
                                                  ('modelnet_attn_head', 'modelnet', {'direct_regress_coor': False})])
 def test_float_restatement_vs_reference_golden(case, cfgn, overrides):
@@ -107,9 +108,10 @@ def test_float_restatement_vs_reference_golden_batch2():
     assert np.abs(out['pose'].numpy() - g['pose']).max() < 5e-5
 
 
-def test_reference_order_pyramid_matches_golden():
-    """Level points of the kitchen pair in the reference's order are bit exact at every level."""
-    g = gold('3dmatch_kitchen')
+@pytest.mark.parametrize('case', ['3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at'])
+def test_reference_order_pyramid_matches_golden(case):
+    """Level points of the shipped 3DMatch pairs in the reference's order are bit exact at every level."""
+    g = gold(case)
     pts = np.concatenate([g['src'], g['tgt']]); lens = np.array([len(g['src']), len(g['tgt'])], np.int32)
     dl = 0.05
     for l in (1, 2, 3):

@@ -113,9 +113,11 @@ def test_neighbour_order_vs_unmodified_reference_cpp(host):
 
 
 @pytest.mark.skipif(not native.have_ref(), reason='oracle/_ref not built (needs /root/reference)')
-def test_neighbour_order_kitchen_pyramid(host):
-    """Every table of the real red-kitchen pair's pyramid (reference row order at every level)."""
-    g = gold('3dmatch_kitchen')
+@pytest.mark.parametrize('case', ['3dmatch_kitchen', '3dmatch_home_at'])
+def test_neighbour_order_kitchen_pyramid(host, case):
+    """Every table of the real red-kitchen / home_at pairs' pyramids (reference row order at every level; home_at is the dense one:
+    22.7 % of level-0 rows are cut at K = 40, so which equidistant supports survive is exercised 2.5x as often)."""
+    g = gold(case)
     pts = np.concatenate([g['src'], g['tgt']]); lens = np.array([len(g['src']), len(g['tgt'])], np.int32)
     r, dl = 0.0625, 0.05
     for l in range(3):
