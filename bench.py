@@ -46,15 +46,12 @@ def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
 def measure_kpconv_roofline(model, batch, reps=5):
     """Times every KPConv gather launch (k_kpconv_gather) with HIP events on the stream it is enqueued on (torch's
     current stream) during real forwards; achieved = sum of algorithmic bytes / sum of durations."""
-    from regtr_amd import ops
+    from regtr_amd import context
     records = []
-    ops.gather_records = records
-    try:
+    with context.recording(gather_records=records):
         for _ in range(reps):
             model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
         torch.cuda.synchronize()
-    finally:
-        ops.gather_records = None
     t_gather = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
     t_gemm = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3
     alg = sum(kpconv_algorithmic_bytes(r[3], r[4], r[5], r[6]) for r in records)
@@ -77,16 +74,13 @@ def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
     """Times every attention-core launch (k_mha_fwd*) with HIP events on its stream during real forwards.  Algorithmic flops
     (SURVEY.md 8d): per layer and pair 4 d (Ns^2 + Nt^2 + 2 Ns Nt) -- QK^T and AV of the two self- and the two
     cross-attentions, d = d_embed."""
-    from regtr_amd import ops
+    from regtr_amd import context
     records = []
-    ops.mha_records = records
-    try:
+    with context.recording(mha_records=records):
         for _ in range(reps):
             b = {'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])}
             model(b)
         torch.cuda.synchronize()
-    finally:
-        ops.mha_records = None
     lens = b['kpconv_meta']['_lens_host'][-1]
     B = len(lens) // 2
     flops_fwd = n_layers * sum(4.0 * d_embed * (lens[i] ** 2 + lens[B + i] ** 2 + 2.0 * lens[i] * lens[B + i]) for i in range(B))
@@ -245,20 +239,22 @@ def parity_check(cfg, model, pairs, out, which, parity_mode=False):
     Quantities: /root/reference/src/models/regtr.py:185-235 (pose, correspondences, overlap logits), utils/se3_torch.py:108-154.
     The oracle is the CHECKER here (outside the timed region), never the thing measured.
 
-    Gate (the run fails otherwise): key points bit-exact, correspondences within 1e-4, and R|t within 1e-4 of the oracle's.  One
-    documented allowance on the pose: with RANDOM-INIT weights (there are no checkpoints here) the predicted correspondences nearly
-    collapse (spread 1.5 cm against 50 cm of key-point spread), so the Kabsch covariance is close to rank one -- singular values
-    0.5 / 1e-3 / 2e-5 measured -- and R amplifies a 1e-6 correspondence difference by 1 / (s2 + s3) ~ 1e2; the reference's own
-    float32 Kabsch then differs from a float64 solve of the SAME inputs by up to 1.6e-5.  So a pose difference above 1e-4 is
-    attributed to conditioning -- and reported as such, with the numbers -- only if the correspondences are within 1e-4, the problem
-    is ill-conditioned (s1 / (s2 + s3) > 50) AND the product's pose agrees within 1e-4 with a float64 Kabsch of its OWN
-    correspondences and weights (so the Procrustes kernel itself is right).  Otherwise it fails."""
+    Gate: key points bit-exact, correspondences within 1e-4 AND R|t within 1e-4 of the oracle's, on every checked pair -- nothing
+    else makes `ok` true.  With RANDOM-INIT weights (there are no checkpoints here) the predicted correspondences nearly collapse
+    (spread 1.5 cm against 50 cm of key-point spread), so the Kabsch covariance is close to rank one -- singular values 0.5 / 1e-3 /
+    2e-5 measured -- and R amplifies a 1e-6 correspondence difference by 1 / (s2 + s3) ~ 1e2; the reference's own float32 Kabsch then
+    differs from a float64 solve of the SAME inputs by up to 1.6e-5 (`oracle_f32_vs_f64_kabsch`).  A pose above 1e-4 on such a pair is
+    therefore DIAGNOSED, not excused: `ok` is false and `reason` says 'conditioning' when the correspondences are within 1e-4, the problem
+    is ill-conditioned (s1 / (s2 + s3) > 50) and the product's pose agrees within 1e-4 with a float64 Kabsch of its OWN correspondences
+    and weights (so the Procrustes kernel itself is right); any other failure says 'mismatch'.  Either way the run reports ok: false
+    and exits non-zero in the float32 modes."""
     from oracle import canonical, native, regtr_ref
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     torch.set_num_threads(max(1, min(usable_cores(), 16)))
     worst = {'pose_max_abs': 0.0, 'corr_max_abs': 0.0, 'overlap_logit_max_abs': 0.0, 'pose_vs_f64_kabsch_of_own_outputs': 0.0,
              'oracle_f32_vs_f64_kabsch': 0.0, 'kabsch_cond_max': 0.0}
-    kp_exact, pose_ok = True, True
+    kp_exact, conditioning_only = True, True
+    per_pair = []
     t0 = time.perf_counter()
     for b in which:
         s, t = pairs[b]
@@ -290,15 +286,33 @@ def parity_check(cfg, model, pairs, out, which, parity_mode=False):
         for k, v in (('pose_max_abs', e_pose), ('corr_max_abs', e_corr), ('overlap_logit_max_abs', e_logit), ('kabsch_cond_max', cond),
                      ('pose_vs_f64_kabsch_of_own_outputs', e_own), ('oracle_f32_vs_f64_kabsch', float((ref['pose'][:, 0].double() - p64_ref).abs().max()))):
             worst[k] = max(worst[k], v)
-        pose_ok = pose_ok and (e_pose < PARITY_TOL or (e_corr < PARITY_TOL and cond > 50.0 and e_own < PARITY_TOL))
-    direct = worst['pose_max_abs'] < PARITY_TOL
-    ok = kp_exact and worst['corr_max_abs'] < PARITY_TOL and pose_ok
-    return dict(worst, pairs_checked=len(which), pair_slots=list(which), keypoints_bit_exact=kp_exact, tol=PARITY_TOL, ok=bool(ok),
-                pose_gate='direct (R|t within tol of the oracle)' if direct else 'conditioning allowance (see bench.py: parity_check)',
+        per_pair.append({'slot': int(b), 'points': [len(s), len(t)], 'pose': e_pose, 'corr': e_corr, 'cond': round(cond, 1)})
+        if e_pose >= PARITY_TOL and not (e_corr < PARITY_TOL and cond > 50.0 and e_own < PARITY_TOL):
+            conditioning_only = False
+    ok = kp_exact and worst['corr_max_abs'] < PARITY_TOL and worst['pose_max_abs'] < PARITY_TOL
+    reason = None
+    if not ok:
+        reason = ('conditioning: correspondences within tol, Kabsch ill-conditioned (s1 / (s2 + s3) > 50) and the pose equals a float64 Kabsch of '
+                  'the product\'s own correspondences within tol -- the float32 pose of a near-rank-one problem, not a kernel defect'
+                  if (kp_exact and worst['corr_max_abs'] < PARITY_TOL and conditioning_only) else 'mismatch')
+    return dict(worst, pairs_checked=len(which), pair_slots=list(which), keypoints_bit_exact=kp_exact, tol=PARITY_TOL, ok=bool(ok), reason=reason,
+                pose_gate='direct: R|t within tol of the oracle on every checked pair', per_pair=per_pair,
                 vs=('CPU oracle (oracle/regtr_ref.py, pinned to the reference module) per pair, ' +
                     ('reference row / tie orders (oracle/_ref), product in parity mode' if parity_mode else
                      'canonical tables from ' + ('the unmodified reference C++ neighbour sets (oracle/_ref)' if native.have_ref() else 'the C++ restatement'))),
                 what='outputs of the last timed step; random-init weights', seconds=round(time.perf_counter() - t0, 2))
+
+
+def parity_slots(sizes, n):
+    """Which slots of a forward's batch the parity check takes: the first and the last (packing offsets at both ends), the largest and
+    the smallest pair (by points), then evenly spaced others up to `n`."""
+    m = len(sizes)
+    want = [0, m - 1, int(np.argmax(sizes)), int(np.argmin(sizes))]
+    slots = []
+    for sl in want + [int(round(i * (m - 1) / max(n, 1))) for i in range(1, n + 1)] + list(range(m)):
+        if sl not in slots and len(slots) < min(n, m):
+            slots.append(sl)
+    return sorted(slots)
 
 
 def plan_pairs(args, rank, world, device):
@@ -325,7 +339,8 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     rank through ONE all_gather (regtr_amd/distributed.py) -- per pass over the set for lomatch, once at the end of the timed region
     otherwise.  step() -> (poses (n_local, 3, 4) of this rank's pairs, anything).  -> (elapsed s, all poses, all ids, last step's extra)"""
     from regtr_amd.distributed import gather_poses
-    gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
+    n_set = args.total_pairs if lomatch else None        # (weak scaling: every rank holds the same count)
+    gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids, n_set)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
     for _ in range(args.warmup):
         step()
     sync()
@@ -341,11 +356,14 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     sync()
     if dist: dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist:
+    per_rank = [elapsed]
+    if dist:       # (outside the timed region) every rank's own clock, so a straggler is visible; the reported time is the MAX
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    return elapsed, gathered[0], gathered[1], extra
+        every = torch.empty(dist.get_world_size(), device=device, dtype=torch.float64)
+        dist.all_gather_into_tensor(every, tt)
+        per_rank = [float(v) for v in every.cpu()]
+        elapsed = max(per_rank)
+    return elapsed, gathered[0], gathered[1], extra, per_rank
 
 
 def count_ranks(all_ids, lomatch, per_fwd, world):
@@ -363,7 +381,7 @@ def run_stub(args, rank, world, dist):
 
     def step():
         return torch.cat([eye + pair_ids[lo:hi, None, None].float() for lo, hi in chunks]), None
-    elapsed, all_poses, all_ids, _ = timed_passes(args, dist, lomatch, pair_ids, step, lambda: None, cpu)
+    elapsed, all_poses, all_ids, _, per_rank = timed_passes(args, dist, lomatch, pair_ids, step, lambda: None, cpu)
     ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)
     assert all_poses.shape[0] == pairs_per_step and ranks_seen == world
     assert torch.equal(all_poses[:, 0], 1 + all_ids.float())
@@ -371,7 +389,8 @@ def run_stub(args, rank, world, dist):
     if rank == 0:
         print(json.dumps({'metric': 'stub', 'value': args.steps * pairs_per_step / max(elapsed, 1e-9), 'unit': 'pairs/s',
                           'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'pairs_per_step': pairs_per_step,
-                          'forwards_per_step_rank0': len(chunks), 'scaling': 'strong' if lomatch else 'weak'}))
+                          'forwards_per_step_rank0': len(chunks), 'scaling': 'strong' if lomatch else 'weak',
+                          'per_rank_ms_per_step': [t / args.steps * 1e3 for t in per_rank]}))
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -388,13 +407,14 @@ def main():
     ap.add_argument('--total-pairs', type=int, default=1781, help='lomatch: size of the pair set (3DLoMatch test list: 1781)')
     ap.add_argument('--distinct-pairs', type=int, default=128, help='lomatch: different synthetic pairs generated per rank (cycled; set-up time only)')
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
-    ap.add_argument('--parity-pairs', type=int, default=2, help='pairs of the last timed step checked against the CPU oracle (0 = off)')
+    ap.add_argument('--parity-pairs', type=int, default=8, help='pairs of the last timed step checked against the CPU oracle: first, last, largest, smallest slot of the batch + evenly spaced others (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
     ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-strict-f32', action='store_true', help="skip the side measurement of compute_dtype 'fp32x3' on the same workload")
     ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
     ap.add_argument('--cpu-baseline-only', action='store_true',
                     help='no GPU needed: time only the CPU baseline leg on the synthetic workload and print it (where /root/reference '
@@ -427,8 +447,8 @@ def main():
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs')
     stub = args.stub_backend is not None      # tests only: the multi-process entry logic on CPU (gloo), no kernels
     dist = None
-    if world > 1:
-        import torch.distributed as dist
+    if world > 1 or 'RANK' in os.environ:        # launched by torch.distributed.run: a process group even at one rank (RCCL init, the
+        import torch.distributed as dist        # device-tensor all_gather) -- the same code path at every world size
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         if stub:
@@ -455,7 +475,7 @@ def main():
             out = model({'src_xyz': batch['src_xyz'][lo:hi], 'tgt_xyz': batch['tgt_xyz'][lo:hi]})
             poses.append(out['pose'][-1])
         return (poses[0] if len(poses) == 1 else torch.cat(poses)), out
-    elapsed, all_poses, all_ids, last_out = timed_passes(args, dist, lomatch, pair_ids, step, torch.cuda.synchronize, dev)
+    elapsed, all_poses, all_ids, last_out, per_rank = timed_passes(args, dist, lomatch, pair_ids, step, torch.cuda.synchronize, dev)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30       # inputs, weights and every buffer of the forwards so far
     assert all_poses.shape[0] == pairs_per_step and torch.isfinite(all_poses).all()
     ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)                                      # who entered the all_gather
@@ -482,10 +502,12 @@ def main():
         res = {
             'metric': metric, 'value': total_pairs / elapsed, 'unit': 'pairs/s',
             'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None, 'dtype': {'fp32': 'f32', 'fp32x3': 'f32'}.get(dtype, dtype), 'data': 'synthetic',
+            'per_rank_ms_per_step': [round(t / args.steps * 1e3, 3) for t in per_rank],
+            'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None,
+            'dtype': {'fp32': 'f32 (f16-pair split, 22-bit operands)', 'fp32x3': 'f32 (bf16x3 split, 24-bit operands)'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
                        'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
-                       'parallelism': f'pair-sharded x{world}, one RCCL pose all_gather', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
+                       'parallelism': f'pair-sharded x{world}, ONE RCCL all_gather_into_tensor of the (pose | id) rows', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
                        'arithmetic': {'fp32': 'float32-grade: exact operand splits on the 16-bit matrix cores (f16 pair, three MFMA terms, where the strip GEMM / attention '
                                               'kernels serve the shape; bf16x3, six terms, elsewhere), float32 accumulation; exact-f32 MFMA in the KPConv gather',
                                       'fp32x3': 'float32-grade: bf16x3 operand splits (six MFMA terms) everywhere, float32 accumulation',
@@ -495,7 +517,7 @@ def main():
         if args.parity_pairs > 0:
             # "pose err vs ref" (BASELINE.json metric): the last timed forward's outputs against the CPU oracle, >= 2 pairs
             lo, hi = chunks[-1]
-            slots = sorted({0, hi - lo - 1} | set(range(1, min(args.parity_pairs, hi - lo) - 1)))
+            slots = parity_slots([len(a) + len(b) for a, b in pairs[lo:hi]], args.parity_pairs)
             res['parity'] = parity_check(cfg, model, pairs[lo:hi], last_out, slots, args.parity_mode)
             res['parity']['enforced'] = dtype in ('fp32', 'fp32x3')      # 'bf16' reports the error; the 1e-4 gate is the float32 modes'
         fwd_batch = {k: v[chunks[0][0]:chunks[0][1]] for k, v in batch.items()}
@@ -530,6 +552,25 @@ def main():
                 'vs': 'float32-grade run of the same weights / pairs', 'pairs': nb,
                 'max_abs_correspondence': max(float((olo['src_kp_warped'][b] - o32['src_kp_warped'][b]).abs().max()) for b in range(nb)),
                 'max_abs_pose': float((olo['pose'] - o32['pose']).abs().max())}
+        if dtype == 'fp32' and world == 1 and not args.no_strict_f32 and not args.parity_mode:
+            # the same workload with strictly 24-bit operands (compute_dtype 'fp32x3': six-term bf16 splits everywhere), quoted beside the
+            # default line whose dense operands carry 22 bits: same weights, same batch, measured here, outside the timed region
+            from regtr_amd import RegTR
+            cfg3 = cfg.copy() if hasattr(cfg, 'copy') else cfg
+            cfg3.update({'compute_dtype': 'fp32x3'})
+            m3 = RegTR(cfg3).to(dev).eval()
+            m3.load_state_dict(model.state_dict())
+            cfg.update({'compute_dtype': dtype})
+            k3 = max(2, min(args.steps, 8))
+            for _ in range(2):
+                m3(dict(fwd_batch))
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            for _ in range(k3):
+                o3 = m3(dict(fwd_batch))
+            torch.cuda.synchronize(); t3 = (time.perf_counter() - t3) / k3
+            res['config']['fp32x3_same_workload'] = {'value': len(fwd_batch['src_xyz']) / t3, 'unit': 'pairs/s', 'ms_per_step': t3 * 1e3, 'steps': k3,
+                                                     'max_abs_pose_vs_default': float((o3['pose'] - model(dict(fwd_batch))['pose']).abs().max())}
+            del m3
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
             res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(24 if args.config == 'modelnet' else 6)],
                                                cfg_name='3dmatch' if lomatch else args.config)

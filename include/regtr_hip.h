@@ -53,8 +53,17 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 8
+#define REGTR_ABI_VERSION 9
 int regtr_abi_version(void);
+
+/* The STATUS WORD: an optional device int (zeroed by the caller, e.g. once per forward) that kernels OR bits into -- conditions that
+ * only the data can reveal, reported without a host round trip per launch.  `status` arguments may be NULL.
+ *   REGTR_STATUS_F16_RANGE       an f16 pair product (regtr_gemm_x3 with n_planes = 4, regtr_mha_fwd precision 3) came out non-finite:
+ *                                an operand reached f16's range (|x| >= 65504).  The caller re-runs in the bf16x3 format (n_planes 3 /
+ *                                precision 0), which has float32's range; regtr_amd.RegTR.forward does, once per forward.
+ *   REGTR_STATUS_NONFINITE_POSE  regtr_weighted_procrustes wrote a non-finite R|t (whatever the cause upstream). */
+#define REGTR_STATUS_F16_RANGE 1
+#define REGTR_STATUS_NONFINITE_POSE 2
 
 /* ---- preprocessing ---------------------------------------------------------------------------------------- */
 
@@ -148,14 +157,6 @@ int regtr_kdtree_radius_query(const float* q_xyz, const int* q_seg_off, int nq_c
 int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, const int* seg_off, int n_seg, float slope,
                           float* flag, void* stream);
 
-/* The deep-level gather on the f16 matrix pipe (Cin a multiple of 64, H <= 40): feature rows as f16 pair planes [n][2][Cin]
- * (regtr_f16_pair_planes of the normalised float32 features: x = h0 + h1 / 2048, the same 4 bytes per value), staged in LDS and read back
- * transposed (ds_read_b64_tr_b16) as v_mfma_f32_16x16x32_f16 operands; float32-grade like regtr_kpconv_gather, operands below 65504. */
-int regtr_f16_pair_planes(const float* x, int n, int C, void* planes, void* stream);
-int regtr_kpconv_gather_f16_supported(int Cin, int H, int KP);
-int regtr_kpconv_gather_f16(const float* q_xyz, int nq, int ns, const int* nbr, int H, const void* x_planes, int Cin, const float* s_xyzf,
-                            const float* kernel_points, int KP, float extent, float* wf, float* num, void* stream);
-
 /* 1 when regtr_kpconv_gather derives the positivity flags from the feature rows it gathers anyway (Cin == 1 or a
  * multiple of 32 with H <= 64, 16-byte aligned x / wf / x_stats): `flag` may then be NULL and regtr_rowsum_positive skipped. */
 int regtr_kpconv_gather_computes_flag(int Cin, int H);
@@ -172,15 +173,6 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
                         int Cin, const float* flag, const float* s_xyzf, const float* kernel_points, int KP, float extent,
                         const float* x_stats, const int* q_seg_off, int n_seg, float slope, float* wf, int ld_wf, float* num,
                         void* stream);
-
-/* KPConv.forward (kpconv_blocks.py:269-414) in ONE launch for the level-0 shape -- 32 -> 32 channels, 15 kernel points, rows of at
- * most 40 neighbours (regtr_kpconv_fused_supported): gather, kernel-point correlation, contraction with W [480,32] and the division
- * by the neighbour count, the weighted features staying in LDS (they are 4.6 GB per convolution of a 64-pair forward otherwise).
- * x [ns,32]: FINAL features; s_xyzf [ns,4]: (x, y, z, positivity flag) records (regtr_instnorm_apply's row_xyz form);
- * planes = regtr_gemm_split_weights(W as [480,32], transposed = 1).  out [nq,32]. */
-int regtr_kpconv_fused_supported(int Cin, int Cout, int KP, int H);
-int regtr_kpconv_fused(const float* q_xyz, int nq, int ns, const int* nbr, int H, const float* x, const float* s_xyzf,
-                       const float* kernel_points, int KP, float extent, const void* planes, float* out, void* stream);
 
 /* out[q,:] = max over the first H columns of row q of nbr (row stride ld_nbr >= H) of x[nbr[q,h],:], the shadow index
  * ns standing for a zero row (kpconv_blocks.py:127-143).  H < ld_nbr serves the reference's CPU tables, whose width is
@@ -224,17 +216,18 @@ int regtr_gemm_split_weights(const float* W, int ld, int N, int K, int transpose
  * bits in two planes; a product is three v_mfma_f32_32x32x16_f16 (the two low terms in a second, scaled accumulator) at float32-grade
  * accuracy (error vs float64 within 3x of the six-term bf16 split's on RegTR's shapes), half the matrix-pipe work of the bf16 split.
  * Operands must stay below 65504 in magnitude.  regtr_gemm_x3_f16_supported(M, N, K, with_stats): every shape regtr_gemm_x3 supports. */
-int regtr_gemm_x3_f16_supported(int M, int N, int K, int with_stats);      /* with_stats: the call passes stat_partial */
+int regtr_gemm_x3_f16_supported(int M, int N, int K, int with_stats);      /* with_stats: the call passes stat_partial, a_stats or tile_info
+                                                                             * (the launch then keeps regtr_gemm_x3_tile_rows' tile height) */
 size_t regtr_gemm_split_weights_f16_bytes(int N, int K);
 int regtr_gemm_split_weights_f16(const float* W, int ld, int N, int K, int transposed, void* planes, void* stream);
 size_t regtr_gemm_x3_ws_bytes(int M, int N, int K);
-/* diagnostic: resident workgroups per CU of the row-strip split kernel (cw 2|4 column blocks, ar 2|3|4 A-ring mode, stats epilogue) */
-int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats);
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, void* stream);
-/* tile_info (optional): regtr_tile_segments(seg_off, n_seg, M, regtr_gemm_x3_tile_rows(M,N,K), ..) -- 16 bytes per row tile that
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, int* status,
+                  void* stream);
+/* status (optional): the status word above; n_planes = 4 reports REGTR_STATUS_F16_RANGE.
+ * tile_info (optional): regtr_tile_segments(seg_off, n_seg, M, regtr_gemm_x3_tile_rows(M,N,K), ..) -- 16 bytes per row tile that
  * replace the per-workgroup cloud search (a chain of dependent memory round trips) when a_stats / stat_partial are used; a_seg_off
  * and stat_seg_off must then be the same array. */
 int regtr_tile_segments(const int* seg_off, int n_seg, int M, int rows, void* out, void* stream);
@@ -271,16 +264,6 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
                      int M, int N, int K1, int K2, float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes,
                      float* out_stats, void* stream);
 
-/* The same tail when the second summand already exists as an [M, N] array R (identity shortcut: r_stats NULL) or is a shortcut product
- * with its own statistics r_stats [n_clouds, N, 2]:  Y = LeakyReLU_slope( InstanceNorm(A1' W1) + [InstanceNorm](R) ), A1' =
- * LeakyReLU_a1_slope(InstanceNorm(A1)) by a1_stats [n_clouds, K1, 2] (kpconv_blocks.py:727-741).  A1' W1 is never written.
- * Shape served: K1 = 64, N % 64 == 0.  tile_info = regtr_tile_segments(seg_off, n_clouds, M, 256, ..). */
-int regtr_block_tail_res_supported(int M, int N, int K1);
-size_t regtr_block_tail_res_ws_bytes(int n_clouds, int max_len, int N, int K1);
-int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float a1_slope, const float* W1, const float* R, int ldr,
-                         const float* r_stats, const int* seg_off, int n_clouds, int max_len, const void* tile_info, int M, int N, int K1,
-                         float eps, float slope, float* Y, int ldy, void* ws, size_t ws_bytes, void* stream);
-
 /* InstanceNorm statistics of C straight from the GEMM epilogue (no second pass over C): when
  * R = regtr_gemm_x3_stat_tile_rows(M,N,K) > 0, pass stat_partial = (ceil(M/R) + n_stat_seg) * N * 2 doubles and the cloud
  * offsets of C's rows; then regtr_instnorm_finalize_tiles(stat_partial, seg_off, n_clouds, N, R, eps, stats) yields the
@@ -307,7 +290,7 @@ int regtr_posemb_sine(const float* xyz, int n, int npf, int d_model, float scale
  * q, k, v are projections of LayerNorm outputs, the probabilities are <= 1; what cfg.compute_dtype 'fp32' uses). */
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
-                  int precision, void* stream);
+                  int precision, int* status, void* stream);      /* status: optional status word (precision 3 reports REGTR_STATUS_F16_RANGE) */
 
 /* The whole pre-norm cross-encoder stack (transformers.py:183-244 forward_pre for every layer, :37-59 the final norm of every
  * layer's output) enqueued by one call -- the same launches, in the same order, as calling regtr_layernorm / regtr_gemm_x3 /
@@ -328,7 +311,7 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
                             const void* const* layer_params, const float* layer_eps, const float* final_gamma,
                             const float* final_beta, float final_eps, int return_intermediate, const float* pe,
                             const int* seg_off, const int* kv_self, const int* kv_cross, int n_clouds, int max_len,
-                            int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, void* stream);
+                            int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, int* status, void* stream);
 
 /* CorrespondenceDecoder.simple_attention (regtr.py:316-351, `direct_regress_coor: False`): single-head attention whose values
  * are coordinates.  q, k [n_layers, n_total, head_dim] contiguous (projections of the conditioned features), xyz [n_total,3],
@@ -336,9 +319,10 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
 int regtr_attn_xyz(const float* q, const float* k, const float* xyz, float* out, const int* seg_off, const int* kv_of,
                    int n_clouds, int n_total, int n_layers, int max_len, int head_dim, float scale, void* stream);
 
-/* kp [n_total,3], corr [L,n_total,3], logit [L,n_total], seg_off [2*n_pairs+1] -> pose [L,n_pairs,3,4] */
+/* kp [n_total,3], corr [L,n_total,3], logit [L,n_total], seg_off [2*n_pairs+1] -> pose [L,n_pairs,3,4]; status (optional): the
+ * status word, REGTR_STATUS_NONFINITE_POSE when an R|t came out non-finite */
 int regtr_weighted_procrustes(const float* kp, const float* corr, const float* logit, const int* seg_off, int n_pairs,
-                              int n_total, int n_layers, float* pose, void* stream);
+                              int n_total, int n_layers, float* pose, int* status, void* stream);
 
 #ifdef __cplusplus
 }

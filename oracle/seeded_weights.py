@@ -108,3 +108,32 @@ def seeded_state_dict(cfg, seed=0, kernel_dispositions=None):
             v = rng.uniform(-bound, bound, shape).astype(np.float32)
         sd[name] = torch.from_numpy(v)
     return sd
+
+
+def trained_like(sd, seed=1, linear_gain=4.0, gain_sigma=0.5):
+    """A checkpoint-like perturbation of a seeded state_dict (random-init magnitudes are far tamer than trained ones): every dense
+    weight of the cross-encoder times `linear_gain` (sharper softmax, larger FFN activations), per-channel log-normal gains
+    (sigma `gain_sigma`) and N(0, 0.3) offsets on every LayerNorm, per-input-channel log-normal gains on the encoder's unary and
+    KPConv weights (InstanceNorm removes a per-output-channel scale, not a spread over the inputs it mixes), feat_proj times 2.  The
+    correspondence head keeps its scale so that outputs stay metre-sized and the 1e-4 absolute bar keeps its meaning."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, v in sd.items():
+        v = v.clone()
+        if name.endswith('kernel_points') or name.startswith('feature_criterion'):
+            pass
+        elif 'norm' in name:
+            if name.endswith('weight'):
+                v = v * torch.from_numpy(np.exp(gain_sigma * rng.standard_normal(v.shape)).astype(np.float32))
+            else:
+                v = v + torch.from_numpy((0.3 * rng.standard_normal(v.shape)).astype(np.float32))
+        elif name.startswith('transformer_encoder.layers') and name.endswith('weight'):
+            v = v * linear_gain
+        elif name.startswith('kpf_encoder') and (name.endswith('mlp.weight') or name.endswith('KPConv.weights')):
+            # gains over the INPUT channels (the following InstanceNorm removes any per-output-channel scale)
+            g = torch.from_numpy(np.exp(gain_sigma * rng.standard_normal(v.shape[1])).astype(np.float32))
+            v = v * (g[None, :, None] if name.endswith('KPConv.weights') else g[None, :])
+        elif name == 'feat_proj.weight':
+            v = v * 2.0
+        out[name] = v
+    return out

@@ -5,8 +5,11 @@ silently pass on some other code path.
 """
 import ctypes
 import os
+import threading
 
 import torch
+
+from . import context
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libregtr_hip.so')
@@ -20,7 +23,7 @@ _F = _c.c_float
 _Z = _c.c_size_t
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 8          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 9          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -39,9 +42,6 @@ SIGNATURES = {
     'regtr_nearest_in_radius': (_I, [_P, _P, _I, _P, _I, _I, _c.c_double, _F, _P, _Z, _P, _P]),
     'regtr_overlap_avgpool': (_I, [_P, _I, _P, _I, _I, _I, _P, _P]),
     'regtr_rowsum_positive': (_I, [_P, _I, _I, _P, _P, _I, _F, _P, _P]),
-    'regtr_f16_pair_planes': (_I, [_P, _I, _I, _P, _P]),
-    'regtr_kpconv_gather_f16_supported': (_I, [_I, _I, _I]),
-    'regtr_kpconv_gather_f16': (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_kpconv_gather_computes_flag': (_I, [_I, _I]),
     'regtr_kpconv_gather': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _I, _F, _P, _I, _P, _P]),
     'regtr_maxpool_gather': (_I, [_P, _I, _I, _P, _I, _I, _I, _P, _P]),
@@ -58,48 +58,65 @@ SIGNATURES = {
     'regtr_gemm_split_weights_f16_bytes': (_Z, [_I, _I]),
     'regtr_gemm_split_weights_f16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'regtr_gemm_x3_ws_bytes': (_Z, [_I, _I, _I]),
-    'regtr_gemm_x3_strip_occupancy': (_I, [_I, _I, _I]),
-    'regtr_gemm_x3': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P, _P, _I, _I, _P, _P]),
+    'regtr_gemm_x3': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P, _P, _I, _F, _P, _Z, _P, _P, _I, _I, _P, _P, _P]),
     'regtr_tile_segments': (_I, [_P, _I, _I, _I, _P, _P]),
     'regtr_gemm_x3_tile_rows': (_I, [_I, _I, _I]),
     'regtr_gemm_stream_supported': (_I, [_I, _I, _I]),
     'regtr_gemm_stream_tile_rows': (_I, []),
-    'regtr_kpconv_fused_supported': (_I, [_I, _I, _I, _I]),
-    'regtr_kpconv_fused': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_block_tail_supported': (_I, [_I, _I, _I, _I]),
     'regtr_block_tail_ws_bytes': (_Z, [_I, _I, _I, _I, _I]),
     'regtr_block_tail': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _P, _I, _I, _P, _I, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P, _P]),
-    'regtr_block_tail_res_supported': (_I, [_I, _I, _I]),
-    'regtr_block_tail_res_ws_bytes': (_Z, [_I, _I, _I, _I]),
-    'regtr_block_tail_res': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P]),
     'regtr_gemm_stream': (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _P, _F, _P, _I, _P, _P, _P]),
     'regtr_gemm_x3_stat_tile_rows': (_I, [_I, _I, _I]),
     'regtr_instnorm_finalize_tiles': (_I, [_P, _P, _I, _I, _I, _F, _P, _P]),
     'regtr_add_f32': (_I, [_P, _P, _Z, _P, _P]),
     'regtr_layernorm': (_I, [_P, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'regtr_posemb_sine': (_I, [_P, _I, _I, _I, _F, _P, _P, _P]),
-    'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    'regtr_mha_fwd': (_I, [_P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     'regtr_cross_encoder_per_layer_params': (_I, []),
     'regtr_cross_encoder_supported': (_I, [_I, _I, _I, _I]),
     'regtr_cross_encoder_ws_bytes': (_Z, [_I, _I, _I]),
-    'regtr_cross_encoder_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P]),
+    'regtr_cross_encoder_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
     'regtr_attn_xyz': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
-    'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P]),
+    'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
+}
+
+# include/regtr_hip_experimental.h: measured-slower experiment kernels and diagnostics, outside the ABI version (opt-in switches only)
+EXPERIMENTAL = {
+    'regtr_f16_pair_planes': (_I, [_P, _I, _I, _P, _P]),
+    'regtr_kpconv_gather_f16_supported': (_I, [_I, _I, _I]),
+    'regtr_kpconv_gather_f16': (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_gemm_x3_strip_occupancy': (_I, [_I, _I, _I]),
+    'regtr_kpconv_fused_supported': (_I, [_I, _I, _I, _I]),
+    'regtr_kpconv_fused': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _P]),
+    'regtr_block_tail_res_supported': (_I, [_I, _I, _I]),
+    'regtr_block_tail_res_ws_bytes': (_Z, [_I, _I, _I, _I]),
+    'regtr_block_tail_res': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P]),
 }
 
 _ERR = {-1: 'kernel launch failed', -2: 'invalid argument', -3: 'workspace too small'}
 
 _lib = None
+_load_lock = threading.Lock()
 
 
 def lib():
     global _lib
     if _lib is None:
+        with _load_lock:
+            if _lib is None:
+                _lib = _load()
+    return _lib
+
+
+def _load():
+    _lib = None
+    if True:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m regtr_amd.build` '
                                '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
         _lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(EXPERIMENTAL.items()):
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -116,30 +133,7 @@ def check(status, what):
         raise RuntimeError(f'{what}: {_ERR.get(status, "error")} (status {status})')
 
 
-_active_device = [None]     # device index the enclosing forward pinned with on_device(); None = ask torch
-
-
-class on_device:
-    """`with on_device(dev):` -- makes `dev` the current HIP device for the enclosed launches (kernels are enqueued on
-    torch's current stream OF THE CURRENT DEVICE, so tensors on cuda:1 under a current device 0 would otherwise be launched
-    on the wrong GPU) and lets ptr() verify every tensor argument lives there."""
-
-    def __init__(self, device):
-        self.device = torch.device(device)
-        if self.device.type != 'cuda':
-            raise RuntimeError('regtr_amd ops need GPU tensors (no CPU fallback)')
-        self.index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.ctx = torch.cuda.device(self.index)
-
-    def __enter__(self):
-        self.ctx.__enter__()
-        self.prev = _active_device[0]
-        _active_device[0] = self.index
-        return self
-
-    def __exit__(self, *exc):
-        _active_device[0] = self.prev
-        return self.ctx.__exit__(*exc)
+on_device = context.on_device     # `with on_device(dev):` pins the launch device for the enclosed op calls (thread-local, regtr_amd/context.py)
 
 
 def ptr(t, dtype=torch.float32):
@@ -147,7 +141,7 @@ def ptr(t, dtype=torch.float32):
     unless stated) and live on the GPU the launch goes to.  (Called a few thousand times per forward: three C-level calls.)"""
     if t is None:
         return None
-    dev = _active_device[0]
+    dev = context.current().device_index
     if t.get_device() != (dev if dev is not None else torch.cuda.current_device()) or t.dtype is not dtype or not t.is_contiguous():
         _explain(t, dtype)
     return t.data_ptr()
@@ -160,7 +154,7 @@ def _explain(t, dtype):
         raise RuntimeError(f'regtr_amd op expected a {dtype} tensor, got {t.dtype} (the kernels reinterpret nothing)')
     if not t.is_contiguous():
         raise RuntimeError('regtr_amd ops need contiguous tensors')
-    dev = _active_device[0]
+    dev = context.current().device_index
     raise RuntimeError(f'tensor on {t.device} but the launch device is cuda:{dev if dev is not None else torch.cuda.current_device()}; '
                        'wrap the call in regtr_amd._lib.on_device(tensor.device)')
 
@@ -193,7 +187,7 @@ def stream():
     """hipStream_t (as an int) of torch's current stream on the launch device.  ~200 launches per forward ask: the raw-handle C call
     costs 0.2 us where torch.cuda.current_stream() builds a Stream object through four Python frames (8 us; it was the largest single
     host cost of a one-pair forward, tools/host_profile.py)."""
-    dev = _active_device[0]
+    dev = context.current().device_index
     if _raw_stream is not None:
         return _raw_stream(dev if dev is not None else torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -28,6 +28,7 @@ struct MhaArgs {
     const int* seg_off; const int* kv_of;
     int ldq, ldk, ldv, ldo, n_heads;
     float scale;
+    int* status;      // optional: REGTR_STATUS_F16_RANGE is OR-ed in when the f16 pair core (precision 3) produced a non-finite output
 };
 
 // accumulator register r of half-wave `hi` holds matrix row  (r & 3) + 8 * (r >> 2) + 4 * hi
@@ -451,8 +452,13 @@ __global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
 #endif
 
     if constexpr (F16) {
+        // a q / k / v value beyond f16's range converts to Inf (its residual to NaN): scores, and with them the outputs, come out
+        // non-finite -- reported through the status word (x * 0 is NaN exactly for a non-finite x)
+        float chk = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r++) o[r] += o_lo[r] * (1.0f / MHA_F16_SCALE);
+        for (int r = 0; r < 16; r++) { o[r] += o_lo[r] * (1.0f / MHA_F16_SCALE); chk = fmaf(o[r], 0.f, chk); }
+        chk = fmaf(l_run, 0.f, chk);
+        if (g.status && wave_live && chk != chk) atomicOr(g.status, REGTR_STATUS_F16_RANGE);
     }
     const int qrow = q0 + l31;
     if (wave_live && qrow < q_end) {
@@ -595,13 +601,13 @@ extern "C" {
 // the f16 pair split (two planes, three MFMA terms; operands below 65504: q, k, v are projections of LayerNorm outputs, p <= 1).
 int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, float* out, int ldo,
                   const int* seg_off, const int* kv_of, int n_clouds, int max_len, int n_heads, int head_dim, float scale,
-                  int precision, void* stream)
+                  int precision, int* status, void* stream)
 {
     if (!q || !k || !v || !out || !seg_off || !kv_of || n_clouds < 1 || n_heads < 1 || max_len < 0) return RG_ERR_ARG;
     if (head_dim != HD || precision < 0 || precision > 3) return RG_ERR_ARG;
     if ((ldq | ldk | ldv | ldo) % 4 || (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) % 16)) return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
-    MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale};
+    MhaArgs g{q, k, v, out, seg_off, kv_of, ldq, ldk, ldv, ldo, n_heads, scale, status};
     hipStream_t st = (hipStream_t)stream;
     // Small problems (a pair or two per forward: fewer than two 4-wave workgroups per CU): the single-wave exact-f32 kernel puts
     // four times as many workgroups on the chip and stages K / V without the split -- 32 us against 56 us per launch at one

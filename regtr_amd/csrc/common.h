@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "regtr_hip.h"      // the public C ABI: every definition below is checked against its declaration at compile time
+#include "regtr_hip_experimental.h"      // ... and the opt-in experiment entry points (outside the ABI version)
 
 #define RG_WAVE 64
 

@@ -64,7 +64,7 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
                             const void* const* layer_params, const float* layer_eps, const float* final_gamma,
                             const float* final_beta, float final_eps, int return_intermediate, const float* pe,
                             const int* seg_off, const int* kv_self, const int* kv_cross, int n_clouds, int max_len,
-                            int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, void* stream)
+                            int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, int* status, void* stream)
 {
     if (!x || !layer_params || !layer_eps || !seg_off || !kv_self || !kv_cross || !outs || n_layers < 1 || n_clouds < 1) return RG_ERR_ARG;
     if (!regtr_cross_encoder_supported(n_tok, d_model, d_ff, n_heads)) return RG_ERR_ARG;
@@ -85,7 +85,7 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
 #define CE_TRY(call) do { const int st_ = (call); if (st_ != RG_OK) return st_; } while (0)
     auto gemm = [&](const float* A, int K, const void* W, const void* bias, float* C, int N, const float* residual, int relu) {
         return regtr_gemm_x3(A, K, W, C, N, M, N, K, (const float*)bias, nullptr, residual, residual ? D : 0, relu, nullptr, nullptr, 0,
-                             0.1f, gws, gws_bytes, nullptr, nullptr, 0, gemm_planes, nullptr, stream);
+                             0.1f, gws, gws_bytes, nullptr, nullptr, 0, gemm_planes, nullptr, status, stream);
     };
     auto attention = [&](const float* xin, const void* const* P, int g, int in_w, float eps, const int* kv_of, float* xout) {
         // xout = xin + out_proj( MHA(q = k = v = LN(xin) + pe) )          transformers.py:194-229
@@ -94,7 +94,7 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
         st = gemm(x2p, D, P[in_w], P[in_w + 1], qkv, 3 * D, nullptr, 0);
         if (st != RG_OK) return st;
         st = regtr_mha_fwd(qkv, 3 * D, qkv + D, 3 * D, qkv + 2 * D, 3 * D, att, D, seg_off, kv_of, n_clouds, max_len, n_heads, hd, scale,
-                           attn_precision, stream);
+                           attn_precision, status, stream);
         if (st != RG_OK) return st;
         return gemm(att, D, P[in_w + 2], P[in_w + 3], xout, D, xin, 0);
     };

@@ -40,6 +40,16 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Development switches of the tile planner (A/B sweeps: tools/x3_bench.py): read from the environment ONLY in variant builds
+// (REGTR_VARIANT_FLAGS=-DREGTR_DEV_ENV=1, regtr_amd/build.py); the shipped library compiles them to their defaults, so a stray
+// environment variable cannot change production tiling.
+#if defined(REGTR_DEV_ENV) && REGTR_DEV_ENV
+static inline int x3_dev_env(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+#define X3_DEV_ENV(NAME, DFLT) x3_dev_env(NAME, DFLT)
+#else
+#define X3_DEV_ENV(NAME, DFLT) (DFLT)
+#endif
+
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -62,7 +72,15 @@ struct X3Args {
     size_t plane;                // elements per weight plane = Npad * Kp
     int M, N, K, Kp, lda, ldc, ldr, act, n_seg, k_chunk, n_stat_seg;
     float a_slope;
+    int* status;                 // optional: REGTR_STATUS_F16_RANGE is OR-ed in when an f16 pair product came out non-finite
 };
+
+// f16 pair: an operand at or beyond f16's range converts to +-Inf and its residual plane to NaN, so every product of that row (or
+// column) is non-finite -- the raw accumulators tell.  x * 0 is 0 for a finite x and NaN otherwise: one FMA per accumulator value.
+__device__ __forceinline__ void x3_report_range(int* status, float chk)
+{
+    if (status && chk != chk) atomicOr(status, REGTR_STATUS_F16_RANGE);
+}
 
 __device__ __forceinline__ unsigned x3_pack(float a, float b)
 {
@@ -317,12 +335,14 @@ __global__ void __launch_bounds__(64 * MW * NW, (MW * NW >= 8) ? 4 : 2) k_gemm_x
     }
 
     if constexpr (FMT == 1) {                              // f16 pair: fold the scaled low terms in
+        float chk = 0.f;
 #pragma unroll
         for (int i = 0; i < WM; i++)
 #pragma unroll
             for (int j = 0; j < WN; j++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[i][j][r] += acc_lo[i][j][r] * (1.0f / X3_F16_SCALE);
+                for (int r = 0; r < 16; r++) { acc[i][j][r] += acc_lo[i][j][r] * (1.0f / X3_F16_SCALE); chk = fmaf(acc[i][j][r], 0.f, chk); }
+        x3_report_range(g.status, chk);
     }
     // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5))
 #pragma unroll
@@ -964,10 +984,12 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     // float64 sums on the live accumulators put every statistics variant at the 256-register cliff (the CW = 2 one spilled around the
     // asm loop and broke it).
     if constexpr (FMT == 1) {                              // f16 pair: fold the scaled low terms in
+        float chk = 0.f;
 #pragma unroll
         for (int j = 0; j < CW; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[j][r] += acc_lo[j][r] * (1.0f / X3_F16_SCALE);
+            for (int r = 0; r < 16; r++) { acc[j][r] += acc_lo[j][r] * (1.0f / X3_F16_SCALE); chk = fmaf(acc[j][r], 0.f, chk); }
+        x3_report_range(g.status, chk);
     }
     float* T = (float*)&sm[0];                             // [BM][BN], free after the k loop's last barrier
 #pragma unroll
@@ -1099,9 +1121,9 @@ X3Plan x3_plan(int M, int N, int K)
 {
     X3Plan p{2, 1, K, false};
     if (N == 32) { p.tile = 1; p.strip = true; return p; }     // thin: one 64-column strip tile per 128 rows (regtr_gemm_x3_supported)
-    static const int strip_on = (getenv("REGTR_X3_STRIP") && *getenv("REGTR_X3_STRIP")) ? atoi(getenv("REGTR_X3_STRIP")) : 1;   // development: A/B runs
-    static const int forced = (getenv("REGTR_X3_TILE") && *getenv("REGTR_X3_TILE")) ? atoi(getenv("REGTR_X3_TILE")) : -1;   // development: tile A/B runs
-    static const int forced_s = (getenv("REGTR_X3_SPLITS") && *getenv("REGTR_X3_SPLITS")) ? atoi(getenv("REGTR_X3_SPLITS")) : 0;   // development
+    static const int strip_on = X3_DEV_ENV("REGTR_X3_STRIP", 1);   // development: A/B runs
+    static const int forced = X3_DEV_ENV("REGTR_X3_TILE", -1);   // development: tile A/B runs
+    static const int forced_s = X3_DEV_ENV("REGTR_X3_SPLITS", 0);   // development
     if (forced >= 0 && forced <= 2 && (forced != 0 || N % 128 == 0)) {
         p.tile = forced;
         p.strip = strip_on && p.tile != 2;
@@ -1268,21 +1290,24 @@ int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
 int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc, int M, int N, int K,
                   const float* bias, const float* row_div, const float* residual, int ldr, int act,
                   const float* a_stats, const int* a_seg_off, int n_seg, float a_slope, void* ws, size_t ws_bytes,
-                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, void* stream)
+                  double* stat_partial, const int* stat_seg_off, int n_stat_seg, int n_planes, const void* tile_info, int* status, void* stream)
 {
     if (!A || !planes || !C || M < 0 || lda < K || ldc < N || !regtr_gemm_x3_supported(M, N, K)) return RG_ERR_ARG;
     if (tile_info && a_stats && stat_partial && (a_seg_off != stat_seg_off || n_seg != n_stat_seg)) return RG_ERR_ARG;
     // n_planes: 1 | 2 | 3 bf16 planes (regtr_gemm_split_weights); 4 = the f16 pair of regtr_gemm_split_weights_f16 (three MFMA terms at
     // float32-grade accuracy; row-strip kernel only: regtr_gemm_x3_f16_supported)
     if (n_planes < 1 || n_planes > 4 || ((n_planes == 1 || n_planes == 2) && (a_stats || stat_partial))) return RG_ERR_ARG;
-    if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K, stat_partial != nullptr)) return RG_ERR_ARG;
+    // (the f16 plan may promote a 64-row plan to 128-row strips; never when a per-tile cloud table or folded statistics ride along --
+    //  tile_info / stat_partial slots are laid out at regtr_gemm_x3_tile_rows' height)
+    const bool f16_keep_rows = stat_partial != nullptr || a_stats != nullptr || tile_info != nullptr;
+    if (n_planes == 4 && !regtr_gemm_x3_f16_supported(M, N, K, f16_keep_rows)) return RG_ERR_ARG;
     if (N == 32 && a_stats) return RG_ERR_ARG;               // the thin case exists on the row-strip kernel only
     if ((lda % 4) || ((uintptr_t)A % 16) || ((uintptr_t)planes % 16)) return RG_ERR_ARG;
     if (a_stats && (!a_seg_off || n_seg < 1 || ((uintptr_t)a_stats % 16))) return RG_ERR_ARG;
     if (M == 0) return RG_OK;
     X3Plan p = x3_plan(M, N, K);
-    if (n_planes == 4) x3_plan_f16(M, N, K, stat_partial != nullptr, p);
-    static const int f16_cw4 = (getenv("REGTR_F16_CW4") && *getenv("REGTR_F16_CW4")) ? atoi(getenv("REGTR_F16_CW4")) : 1;   // development: A/B runs
+    if (n_planes == 4) x3_plan_f16(M, N, K, f16_keep_rows, p);
+    static const int f16_cw4 = X3_DEV_ENV("REGTR_F16_CW4", 1);   // development: A/B runs
     if (n_planes == 4 && p.tile == 0 && !f16_cw4) p.tile = 1;
     // (tiled kernel, f16 pair: the 8-wave 128 x 128 tile's two accumulator sets do not fit its 128-register budget -- 128 x 64 instead;
     //  same 128-row statistics slots)
@@ -1292,7 +1317,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
     X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
              p.splits > 1 ? (float*)ws : nullptr, (double2*)stat_partial, stat_seg_off, (const int4*)tile_info, (size_t)Npad * Kp,
-             M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, n_stat_seg, a_slope};
+             M, N, K, Kp, lda, ldc, ldr, act, n_seg, p.k_chunk, n_stat_seg, a_slope, status};
     hipStream_t st = (hipStream_t)stream;
     const int bm = p.tile == 2 ? 64 : 128, bn = p.tile == 0 ? 128 : 64;
     dim3 grid(rg_cdiv(rg_cdiv(M, bm), 8) * 8 * rg_cdiv(N, bn), 1, p.splits);      // see the XCD-aware tile map in the kernel
@@ -1316,11 +1341,11 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
         else if (stat_partial) k_gemm_x3d<MW_, CW_, AR_, true><<<grid, 64 * MW_, 0, st>>>(g); \
         else k_gemm_x3d<MW_, CW_, AR_, false><<<grid, 64 * MW_, 0, st>>>(g); } while (0)
     const bool strip = p.strip && !a_stats && K % XBK == 0 && p.k_chunk % XBK == 0;
-    static const int a_ring = (getenv("REGTR_X3_ARING") && *getenv("REGTR_X3_ARING")) ? atoi(getenv("REGTR_X3_ARING")) : 3;   // development: A/B runs
+    static const int a_ring = X3_DEV_ENV("REGTR_X3_ARING", 3);   // development: A/B runs
     // (measured and left out: 8 waves on 256 x 128 tiles, 144 KiB of LDS, one workgroup per CU -- k_gemm_x3d<8, 4, 3> -- halves the
     // weight traffic per MFMA and is no faster: 498 vs 483 us on the level-2 contraction, 555 vs 478 at level 3 where 296 tiles
     // quantise badly over 256 CUs)
-    static const int il = (getenv("REGTR_X3_IL") && *getenv("REGTR_X3_IL")) ? atoi(getenv("REGTR_X3_IL")) : 1;   // development: A/B runs
+    static const int il = X3_DEV_ENV("REGTR_X3_IL", 1);   // development: A/B runs
     // Interleaved schedule (A two tiles ahead in TWO slots, every DMA instruction issued between MFMAs) for the 128 x 128 tile: measured
     // on the 18 RegTR shapes (gpurun_out/r03_z5) sum 4716 -> 4670 us, level-3 contraction 472 -> 458 us; on the 128 x 64 tile it loses
     // on the strided contractions (153 -> 165, 145 -> 151 us) and is not instantiated.  Hiding the ~1250-cycle DMA-issue phase bought

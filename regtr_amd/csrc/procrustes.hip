@@ -106,6 +106,7 @@ struct ProArgs {
     const int* seg_off;   // [2B + 1]
     float* pose;          // [L, B, 3, 4]
     int B, n_total;
+    int* status;          // optional: REGTR_STATUS_NONFINITE_POSE is OR-ed in when a pose comes out non-finite
 };
 
 __global__ void __launch_bounds__(PT) k_procrustes(ProArgs g)
@@ -184,11 +185,16 @@ __global__ void __launch_bounds__(PT) k_procrustes(ProArgs g)
                            R[2] * (R[3] * R[7] - R[4] * R[6]);
         if (!(det > 0)) vut(-1.0);
         float* P = g.pose + ((size_t)l * g.B + b) * 12;
+        bool bad = false;
         for (int r = 0; r < 3; r++) {
             const double t = -(R[3 * r] * caf[0] + R[3 * r + 1] * caf[1] + R[3 * r + 2] * caf[2]) + cbf[r];   // :151
             P[4 * r] = (float)R[3 * r]; P[4 * r + 1] = (float)R[3 * r + 1]; P[4 * r + 2] = (float)R[3 * r + 2];
             P[4 * r + 3] = (float)t;
+            bad = bad || !(fabs(R[3 * r]) <= 2.0) || !(fabs(R[3 * r + 1]) <= 2.0) || !(fabs(R[3 * r + 2]) <= 2.0) || !(fabs(t) < 1e30);
         }
+        // a NaN / Inf anywhere upstream (an f16 pair operand out of range that a ReLU or max swallowed on the way, a non-finite input
+        // coordinate) ends here: R|t is the sum over every token of the pair
+        if (bad && g.status) atomicOr(g.status, REGTR_STATUS_NONFINITE_POSE);
     }
 }
 
@@ -199,10 +205,10 @@ extern "C" {
 int regtr_abi_version(void) { return REGTR_ABI_VERSION; }
 
 int regtr_weighted_procrustes(const float* kp, const float* corr, const float* logit, const int* seg_off, int n_pairs,
-                              int n_total, int n_layers, float* pose, void* stream)
+                              int n_total, int n_layers, float* pose, int* status, void* stream)
 {
     if (!kp || !corr || !logit || !seg_off || !pose || n_pairs < 1 || n_layers < 1 || n_total < 0) return RG_ERR_ARG;
-    ProArgs g{kp, corr, logit, seg_off, pose, n_pairs, n_total};
+    ProArgs g{kp, corr, logit, seg_off, pose, n_pairs, n_total, status};
     k_procrustes<<<dim3(n_pairs, n_layers), PT, 0, (hipStream_t)stream>>>(g);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

@@ -1,5 +1,6 @@
 """Pair-level data parallelism: one process per GPU, independent scan pairs sharded across ranks, ONE collective --
-the gather of the per-pair poses (RCCL over xGMI on MI355X; backend "nccl" is RCCL on ROCm, gloo on CPU in tests).
+the gather of the per-pair poses (RCCL over xGMI on MI355X; backend "nccl" is RCCL on ROCm, gloo on CPU in tests): ONE
+all_gather_into_tensor of (pose | pair id) rows padded to the common shard capacity.
 
 The reference has no distributed code at all (single process, one pair per step: trainer.py:177-211, conf
 test_batch_size: 1); this is the shard point its test loop offers.  No collective runs inside the forward.
@@ -13,26 +14,33 @@ def shard_pairs(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def gather_poses(poses, pair_ids):
-    """poses (n_local, 12) f32 and pair_ids (n_local,) i32 of this rank -> every rank gets (n_total, 12), (n_total,)
-    ordered by pair id.  Ranks may hold different counts (ragged shards): counts are exchanged first, buffers padded to
-    the maximum so a single all_gather per tensor suffices."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+def shard_capacity(n_pairs, world):
+    """Largest shard of shard_pairs(n_pairs, ., world): what every rank pads its payload to."""
+    return (n_pairs + world - 1) // world
+
+
+def gather_poses(poses, pair_ids, n_total=None):
+    """poses (n_local, 12) f32 and pair_ids (n_local,) i32 of this rank -> every rank gets (n_total, 12), (n_total,) ordered by pair id.
+    ONE collective: every rank pads its (pose | id) rows to the common capacity ceil(n_total / world) -- known on every rank without
+    talking, since the shards are i % world -- with id = -1 marking padding, and a single all_gather_into_tensor moves the payload; no
+    count exchange, no host read-back before the collective.  n_total: pairs in the whole set (all ranks); may be omitted only when
+    every rank holds the same number of rows (weak scaling: n_total = world * n_local)."""
+    if not (dist.is_available() and dist.is_initialized()):
         order = torch.argsort(pair_ids)
         return poses[order], pair_ids[order]
-    world = dist.get_world_size()
+    world = dist.get_world_size()           # (a one-rank group still runs the collective: same code path at every world size)
     dev = poses.device
-    n_local = torch.tensor([poses.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    counts = [int(c.item()) for c in counts]
-    n_max = max(counts)
-    buf = torch.zeros((n_max, 13), dtype=torch.float32, device=dev)
-    buf[:poses.shape[0], :12] = poses
-    buf[:poses.shape[0], 12] = pair_ids.to(torch.float32)        # ids < 2^24 are exact in f32
-    out = torch.empty((world * n_max, 13), dtype=torch.float32, device=dev)
+    n_local = poses.shape[0]
+    cap = shard_capacity(n_total, world) if n_total is not None else n_local
+    if n_local > cap:
+        raise ValueError(f'gather_poses: {n_local} local rows exceed the shard capacity {cap} of a {n_total}-pair set on {world} ranks')
+    buf = torch.zeros((cap, 13), dtype=torch.float32, device=dev)
+    buf[:, 12] = -1.0                                         # padding rows carry id -1
+    buf[:n_local, :12] = poses
+    buf[:n_local, 12] = pair_ids.to(torch.float32)            # ids < 2^24 are exact in f32
+    out = torch.empty((world * cap, 13), dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(out, buf)
-    rows = torch.cat([out[r * n_max:r * n_max + counts[r]] for r in range(world)])
+    rows = out[out[:, 12] >= 0]
     ids = rows[:, 12].to(torch.int32)
     order = torch.argsort(ids)
     return rows[order, :12].contiguous(), ids[order]

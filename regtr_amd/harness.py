@@ -265,7 +265,7 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
             ids.extend(it['idx'] for it in b['items'])
     pose_t = torch.cat(poses).reshape(-1, 12) if poses else torch.zeros((0, 12), dtype=torch.float32, device=device)
     id_t = torch.tensor(ids, dtype=torch.int32, device=device)
-    all_poses, all_ids = gather_poses(pose_t, id_t)
+    all_poses, all_ids = gather_poses(pose_t, id_t, n)
     if device.type == 'cuda':
         torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
@@ -275,6 +275,7 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
     if not np.isfinite(poses_np).all():
         bad = np.unique(np.nonzero(~np.isfinite(poses_np))[0])
         raise RuntimeError(f'{len(bad)} of {len(poses_np)} predicted poses are not finite (first pair ids: {all_ids.cpu().numpy()[bad[:5]].tolist()}).  '
-                           "Under cfg.compute_dtype 'fp32' the tall contractions use the f16 pair operand split, whose operands must stay below 65504: "
-                           "a checkpoint with larger activations needs compute_dtype: 'fp32x3' (six-term bf16 split, float32's range) or REGTR_F16_PAIR=0")
+                           "(An f16 pair operand beyond 65504 is not the cause unless cfg.f16_range_check was switched off: RegTR.forward detects that "
+                           "and re-runs the forward in fp32x3 arithmetic; compute_dtype: 'fp32x3' avoids the format altogether.)  Check the inputs "
+                           'and the checkpoint for non-finite values.')
     return poses_np, all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world}

@@ -7,7 +7,7 @@ import os
 
 import torch
 
-from . import _lib
+from . import _lib, context
 from ._lib import bptr, check, dptr, iptr, ptr, raw, stream
 
 
@@ -16,6 +16,9 @@ def _ws(nbytes, device):
 
 
 # ------------------------------------------------------------------------------------------------ preprocessing
+F16_OPERAND_LIMIT = 65504.0 / 2     # f16 pair operands: largest finite f16 is 65504; weights are audited with a factor of headroom
+
+
 VOXEL_KEY_MODES = {'origin': 0, 'floor': 1, 'floor_rcp': 2}
 
 
@@ -122,7 +125,7 @@ class SplitWeight:
             self.K, self.N = w.shape
             self.kn = w
         self.planes = None
-        self._w, self._layout, self._planes16 = w, layout, None
+        self._w, self._layout, self._planes16, self._f16_ok = w, layout, None, None
         if L.regtr_gemm_x3_supported(1, self.N, self.K) or L.regtr_gemm_stream_supported(1, self.N, self.K):
             self.planes = _ws(L.regtr_gemm_split_weights_bytes(self.N, self.K), w.device)
             check(L.regtr_gemm_split_weights(ptr(w), w.stride(0), self.N, self.K, 0 if layout == 'nk' else 1, bptr(self.planes),
@@ -130,10 +133,20 @@ class SplitWeight:
 
 
     @property
+    def f16_ok(self):
+        """The weights fit the f16 pair format's range (audited once per weight version: one small reduction + read-back; a weight
+        at or beyond 65504 would make every product non-finite, so such a matrix stays on the bf16x3 planes)."""
+        if self._f16_ok is None:
+            self._f16_ok = bool(self._w.numel() == 0 or float(self._w.abs().max()) < F16_OPERAND_LIMIT)
+        return self._f16_ok
+
+    @property
     def planes16(self):
         """The f16 pair planes of regtr_gemm_split_weights_f16 (regtr_gemm_x3's n_planes = 4), built on first use."""
         if self._planes16 is None:
             L = _lib.lib()
+            if not self.f16_ok:
+                raise RuntimeError('SplitWeight.planes16: a weight of magnitude >= 65504 cannot take the f16 pair format (check .f16_ok)')
             self._planes16 = _ws(L.regtr_gemm_split_weights_f16_bytes(self.N, self.K), self._w.device)
             check(L.regtr_gemm_split_weights_f16(ptr(self._w), self._w.stride(0), self.N, self.K, 0 if self._layout == 'nk' else 1,
                                                  bptr(self._planes16), stream()), 'regtr_gemm_split_weights_f16')
@@ -142,27 +155,19 @@ class SplitWeight:
 
 # float32-grade contractions as three f16 MFMA terms (the f16 pair split, csrc/gemm_x3.hip) where the row-strip kernel serves the shape,
 # instead of six (planes = 3) / three (planes = 2) bf16 terms.  f16_pair_default: what cfg.compute_dtype 'fp32' asks for (A-B runs:
-# REGTR_F16_PAIR=0); use_f16_pair: the switch gemm() reads, set per forward by RegTR (`with ops.f16_pair(flag)`) and by tests.
+# REGTR_F16_PAIR=0).  Whether a given launch takes the format is a field of the per-forward context (context.current().f16_pair, set by
+# RegTR.forward; `with ops.f16_pair(flag):` for tests and direct op calls) -- not a module global: two models on two host threads do not
+# share it.
 f16_pair_default = os.environ.get('REGTR_F16_PAIR', '1') != '0'
 # N = 32 contractions (level 0) on the f16 pair strip kernel: measured 1044 us against 1084 us + 70 us of separate statistics passes on the
 # exact-f32 kernel, 27.71 vs 27.73 ms per forward (gpurun_out/r03_f7) -- both stream the 4.6 GB operand at ~4.4 TB/s; off
 thin_f16_gemm = os.environ.get('REGTR_F16_THIN', '0') != '0'
-use_f16_pair = False
-f16_range_log = None      # a list: gemm() records (M, N, K, max |A|, max |W|) of every f16-pair launch (the format's operands must stay below 65504)
 _f16_shape = {}
 
 
-class f16_pair:
-    def __init__(self, on):
-        self.on = bool(on)
-
-    def __enter__(self):
-        global use_f16_pair
-        self.prev, use_f16_pair = use_f16_pair, self.on
-
-    def __exit__(self, *exc):
-        global use_f16_pair
-        use_f16_pair = self.prev
+def f16_pair(on):
+    """`with ops.f16_pair(True):` -- the enclosed launches (this thread) take the f16 pair format where it is served."""
+    return context.current().derive(f16_pair=bool(on))
 
 
 def f16_pair_ok(M, N, K, with_stats=False):
@@ -219,6 +224,11 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     x3_ok, x3_pref, nb, x3_R, x3_rows = _x3_plan(M, N, K) if sw is not None and sw.planes is not None else (False, False, 0, 0, 0)
     # (N = 32, the level-0 KPConv contractions: a pure A stream on which the six-term bf16 strip loses to the exact-f32 kernel, 1.20 vs 1.14 ms;
     #  the f16 pair's three terms are lighter than both -- thin_f16)
+    ctx = context.current()
+    use_f16_pair = ctx.f16_pair and not ctx.force_x3
+    if ctx.force_x3:
+        planes = 3
+    f16_range_log = ctx.f16_range_log
     thin_f16 = use_f16_pair and thin_f16_gemm and N == 32 and a_stats is None and x3_ok and M >= STREAM_MIN_ROWS and f16_pair_ok(M, N, K, want_stats is not None)
     if (x3_ok and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm and (N >= 64 or a_stats is None)
             and (force_x3_gemm or x3_pref or thin_f16)):
@@ -234,14 +244,14 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
         if seg_rows is not None and use_tile_info and (a_seg_off is None or s_off is None or a_seg_off is s_off):
             ti = tile_segments(seg_rows, M, x3_rows)
         pl, npl = sw.planes, int(planes)
-        if use_f16_pair and npl >= 2 and f16_pair_ok(M, N, K, R > 0):
+        if use_f16_pair and npl >= 2 and sw.f16_ok and f16_pair_ok(M, N, K, R > 0 or a_stats is not None or ti is not None):
             pl, npl = sw.planes16, 4
             if f16_range_log is not None:      # tests / audits: the largest operand magnitude handed to the f16 pair format (synchronises)
                 f16_range_log.append((M, N, K, float(a.abs().max()) if M else 0.0, float(sw.kn.abs().max())))
         check(L.regtr_gemm_x3(raw(a), lda, bptr(pl), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
-                              npl, iptr(ti), stream()), 'regtr_gemm_x3')
+                              npl, iptr(ti), ctx.status_ptr(), stream()), 'regtr_gemm_x3')
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
             check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
@@ -473,7 +483,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
             and nq >= STREAM_MIN_ROWS and L.regtr_kpconv_fused_supported(Cin, w_flat.N, KP, H)
             and x.data_ptr() % 16 == 0 and ns * Cin < (1 << 29)):
         out = torch.empty((nq, w_flat.N), dtype=torch.float32, device=dev)
-        rec = gather_records
+        rec = context.current().gather_records
         if rec is not None:
             e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
             e0.record()
@@ -487,7 +497,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         return out, instnorm_stats(out, want_stats[0], want_stats[1])
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
-    rec = gather_records
+    rec = context.current().gather_records
     if rec is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
@@ -516,8 +526,7 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
 use_f16_gather = os.environ.get('REGTR_F16_GATHER', '0') != '0'
 F16_GATHER_MIN_ROWS = 1
 
-# bench.py sets this to a list to time every KPConv gather launch (HIP events on the launch stream = torch's current one)
-gather_records = None
+# (bench.py times every KPConv gather launch with HIP events on the launch stream: context.recording(gather_records=[...]))
 
 
 def maxpool(x, nbr, width=None):
@@ -565,20 +574,21 @@ def mha(q, k, v, seg_off, kv_of, max_len, n_heads, precision=0):
     N, E = q.shape
     hd = E // n_heads
     out = torch.empty((N, E), dtype=torch.float32, device=q.device)
-    rec = mha_records
+    ctx = context.current()
+    rec = ctx.mha_records
+    if ctx.force_x3 and precision == 3:
+        precision = 0                      # the range fallback: bf16x3 operands (float32's range)
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     check(_lib.lib().regtr_mha_fwd(raw(q), q.stride(0), raw(k), k.stride(0), raw(v), v.stride(0),
                                    ptr(out), E, iptr(seg_off), iptr(kv_of), seg_off.numel() - 1, int(max_len), n_heads, hd,
-                                   1.0 / math.sqrt(hd), int(precision), stream()), 'regtr_mha_fwd')
+                                   1.0 / math.sqrt(hd), int(precision), ctx.status_ptr(), stream()), 'regtr_mha_fwd')
     if rec is not None:
         e1.record()
         rec.append((e0, e1))
     return out
 
-
-mha_records = None      # bench.py: list to time every attention-core launch (HIP events on the launch stream)
 
 
 def attn_xyz(q, k, xyz, seg_off, kv_of, max_len):
@@ -595,5 +605,5 @@ def weighted_procrustes(kp, corr, logit, seg_off, n_pairs):
     Lyr, N = logit.shape
     pose = torch.empty((Lyr, n_pairs, 3, 4), dtype=torch.float32, device=kp.device)
     check(_lib.lib().regtr_weighted_procrustes(ptr(kp), ptr(corr), ptr(logit), iptr(seg_off), n_pairs, N, Lyr, ptr(pose),
-                                               stream()), 'regtr_weighted_procrustes')
+                                               context.current().status_ptr(), stream()), 'regtr_weighted_procrustes')
     return pose

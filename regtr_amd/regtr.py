@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, context, ops
 from .config import as_config
 from .kpconv import KPFEncoder, PreprocessorGPU, _prepared
 from .transformer import TransformerCrossEncoder, TransformerCrossEncoderLayer
@@ -121,20 +121,26 @@ class RegTR(nn.Module):
         encoder_norm = nn.LayerNorm(cfg.d_embed) if cfg.pre_norm else None
         # cfg.compute_dtype (not a reference key).  Every dense contraction runs on the 16-bit matrix cores with EXACT operand splits and
         # float32 accumulation.  'fp32' (default): the f16 PAIR split -- x = h0 + h1 / 2048, three f16 MFMA terms, error ~2^-22 per
-        # product, operands must stay below f16's 65504 (InstanceNorm / LayerNorm outputs and their gathered sums are: largest |A| 116 on
-        # the benchmark workload; a larger value gives a non-finite output, loudly) -- in the split GEMMs and the attention core, the
-        # six-term bf16 split (~2^-24) in the one-shot strip / block-tail kernels of the shallow levels.  Validated against the real
-        # reference module's outputs on all five goldens in parity mode (worst 2.6e-5, bar 1e-4; profiles/r03_dtype_parity.txt) and on
-        # the benchmarked batch (bench.py's `parity`: pose 8.6e-6).  'fp32x3' = six bf16 terms everywhere (full float32 operand range,
-        # no f16); 'bf16x2' = three bf16 terms in the cross-encoder's Linears without the f16 pair (round-2 callers); 'bf16' = plain
-        # bf16 operands with float32 accumulation / softmax in the cross-encoder's Linears and attention core (BASELINE configs[1];
-        # encoder, head, pose as 'fp32').
+        # product, 22-bit operands that must stay below f16's 65504 -- in the split GEMMs and the attention core, the six-term bf16 split
+        # (~2^-24) in the one-shot strip / block-tail kernels of the shallow levels and wherever the f16 format does not serve a launch.
+        # RANGE: InstanceNorm / LayerNorm outputs and their gathered sums sit far below the limit with sane weights (largest |A| 116 on
+        # the benchmark workload), but nothing bounds a checkpoint's FFN activations, so it is CHECKED: weights once per version
+        # (ops.SplitWeight.f16_ok), activations by the kernels themselves -- a non-finite f16 pair product or pose sets a bit in a
+        # device status word that forward() reads once, at its end, and on a trip the forward is re-run in 'fp32x3' arithmetic and the
+        # event logged (cfg.f16_range_check: False skips the check and its end-of-forward wait).  Validated against the real reference
+        # module's outputs on the goldens in parity mode (worst 2.6e-5, bar 1e-4) and on the benchmarked batch (bench.py's `parity`).
+        # 'fp32x3' = six bf16 terms everywhere (float32's operand range, no f16); 'bf16x2' = three bf16 terms in the cross-encoder's
+        # Linears without the f16 pair (round-2 callers); 'bf16' = plain bf16 operands with float32 accumulation / softmax in the
+        # cross-encoder's Linears and attention core (BASELINE configs[1]; encoder, head, pose as 'fp32').
         dt = cfg.get('compute_dtype', 'fp32')
         if dt not in ('fp32', 'fp32x3', 'bf16', 'bf16x2'):
             raise NotImplementedError(f'compute_dtype {dt!r}: choose fp32, fp32x3, bf16x2 or bf16')
-        encoder_layer.gemm_planes = {'fp32': 2, 'fp32x3': 3, 'bf16x2': 2, 'bf16': 1}[dt]
+        # (bf16 planes per operand where the f16 pair does not serve a launch: 'fp32' then means six terms, like 'fp32x3')
+        encoder_layer.gemm_planes = {'fp32': 3, 'fp32x3': 3, 'bf16x2': 2, 'bf16': 1}[dt]
         encoder_layer.attn_precision = 1 if dt == 'bf16' else (3 if (dt == 'fp32' and ops.f16_pair_default) else 0)      # ops.mha's codes
         self._f16_pair = dt in ('fp32', 'bf16') and ops.f16_pair_default      # ('bf16': the encoder / head GEMMs, which stay float32-grade)
+        self._range_check = bool(cfg.get('f16_range_check', True))
+        self.f16_range_fallbacks = 0          # forwards re-run in fp32x3 arithmetic because an f16 pair operand left the format's range
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)
         if cfg.get('direct_regress_coor', False):                                 # :68-73
@@ -155,6 +161,11 @@ class RegTR(nn.Module):
     def load_state_dict(self, *args, **kwargs):
         self._params_checked = False
         return super().load_state_dict(*args, **kwargs)
+
+    def _status_word(self, dev):
+        """(device int32[1], pinned host int32[1]) of this model on `dev`: the status word the kernels of a forward OR bits into."""
+        return _prepared(self._cache, ('status', dev), self.feat_proj.bias,
+                         lambda _: (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory()))
 
     def _side_stream(self, dev):
         return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
@@ -184,8 +195,30 @@ class RegTR(nn.Module):
             self._params_checked = True
         if any(p.device != dev for p in clouds) or self._model_device != dev:
             raise RuntimeError(f'RegTR.forward: the model ({self._model_device}) and every input cloud must live on one GPU ({dev})')
-        # kernels go to torch's current stream of the CURRENT device: make the tensors' device current for the whole forward
-        with _lib.on_device(dev), ops.f16_pair(self._f16_pair):
+        # kernels go to torch's current stream of the CURRENT device: the context makes the tensors' device current for the whole
+        # forward and carries the operand format / status word to every launch (thread-local: regtr_amd/context.py)
+        check = self._f16_pair and self._range_check
+        st_dev, st_host = self._status_word(dev) if check else (None, None)
+        with context.forward(dev, f16_pair=self._f16_pair, status=st_dev):
+            if not check:
+                return self._forward(batch, dev)
+            st_dev.zero_()
+            out = self._forward(batch, dev)
+            st_host.copy_(st_dev, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            done.synchronize()                  # the one wait at the end of a forward: the status word (4 bytes, pinned)
+            bits = int(st_host[0])
+        if bits == 0:
+            return out
+        # an operand left f16's range (or the pose came out non-finite): the same forward in fp32x3 arithmetic -- float32's range
+        self.f16_range_fallbacks += 1
+        if self.f16_range_fallbacks <= 3:
+            self.logger.warning('f16 pair operand range exceeded (status %d: %s) -- forward re-run with six-term bf16 splits '
+                                "(compute_dtype 'fp32x3' arithmetic); set cfg.compute_dtype: fp32x3 to skip the first attempt", bits,
+                                ' + '.join(n for b, n in ((context.STATUS_F16_RANGE, 'non-finite f16 pair product'),
+                                                          (context.STATUS_NONFINITE_POSE, 'non-finite pose')) if bits & b))
+        with context.forward(dev, f16_pair=False, force_x3=True, status=None):
             return self._forward(batch, dev)
 
     def _forward(self, batch, dev):

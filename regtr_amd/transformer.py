@@ -12,7 +12,7 @@ import ctypes
 import torch
 import torch.nn as nn
 
-from . import _lib, ops
+from . import _lib, context, ops
 from .kpconv import _prepared
 
 
@@ -132,7 +132,9 @@ class TransformerCrossEncoder(nn.Module):
     # pair per forward the host is the bound and these are 72 of its ~280 launches (csrc/cross_encoder.hip).
     def _one_call_ok(self, x, pe):
         l0 = self.layers[0]
-        if not (ops.use_one_call_cross_encoder and ops.mha_records is None and ops.f16_range_log is None and not ops.force_f32_gemm and x.dim() == 2 and x.is_contiguous()
+        ctx = context.current()
+        if not (ops.use_one_call_cross_encoder and ctx.mha_records is None and ctx.gemm_records is None and ctx.f16_range_log is None
+                and not ops.force_f32_gemm and x.dim() == 2 and x.is_contiguous()
                 and x.data_ptr() % 16 == 0 and (pe is None or pe.is_contiguous())):
             return False
         for layer in self.layers:
@@ -145,13 +147,22 @@ class TransformerCrossEncoder(nn.Module):
     def _f16_pair(self, n):
         l0 = self.layers[0]
         D, F = l0.d_model, l0.linear1.out_features
-        return bool(ops.use_f16_pair and l0.gemm_planes >= 2 and ops.f16_pair_ok(n, 3 * D, D) and ops.f16_pair_ok(n, D, D)
+        ctx = context.current()
+        return bool(ctx.f16_pair and not ctx.force_x3 and l0.gemm_planes >= 2 and ops.f16_pair_ok(n, 3 * D, D) and ops.f16_pair_ok(n, D, D)
                     and ops.f16_pair_ok(n, F, D) and ops.f16_pair_ok(n, D, F))
 
     def _param_table(self, f16=False):
         """(ctypes array of the layers' device pointers in regtr_cross_encoder_fwd's order, ctypes array of the norm eps) -- rebuilt only
         when a pointer changes; the tensors behind the pointers are kept alive by the modules / the layers' weight caches."""
         ptrs, eps = [], []
+        if f16:       # every weight inside the format's range (audited once per weight version, SplitWeight.f16_ok); else: the bf16 planes
+            for layer in self.layers:
+                m = layer._modules
+                for tag, w in (('sa_in', m['self_attn'].in_proj_weight), ('sa_out', m['self_attn'].out_proj.weight),
+                               ('ca_in', m['multihead_attn'].in_proj_weight), ('ca_out', m['multihead_attn'].out_proj.weight),
+                               ('l1', m['linear1'].weight), ('l2', m['linear2'].weight)):
+                    if not layer._wt(tag, w).f16_ok:
+                        return None, None
         for layer in self.layers:
             m = layer._modules
             sa, ca = m['self_attn'], m['multihead_attn']
@@ -177,8 +188,14 @@ class TransformerCrossEncoder(nn.Module):
         l0 = self.layers[0]
         n, D = x.shape
         F = l0.linear1.out_features
+        ctx = context.current()
         f16 = self._f16_pair(n)
+        planes = 4 if f16 else (3 if ctx.force_x3 else int(l0.gemm_planes))
+        attn_precision = 0 if (ctx.force_x3 and l0.attn_precision == 3) else int(l0.attn_precision)
         table, eps = self._param_table(f16)
+        if table is None:                   # a weight beyond f16's range: the whole stack on the bf16 planes
+            f16, planes = False, (3 if ctx.force_x3 else max(int(l0.gemm_planes), 3 if l0.attn_precision == 3 else 1))
+            table, eps = self._param_table(False)
         nb = L.regtr_cross_encoder_ws_bytes(n, D, F)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
         g = b = None
@@ -187,8 +204,8 @@ class TransformerCrossEncoder(nn.Module):
             g, b, feps = self.norm.weight.detach(), self.norm.bias.detach(), self.norm.eps
         _lib.check(L.regtr_cross_encoder_fwd(_lib.ptr(x), n, D, F, l0.nhead, self.num_layers, table, eps, _lib.ptr(g), _lib.ptr(b), feps,
                                              1 if self.return_intermediate else 0, _lib.ptr(pe), _lib.iptr(seg_off), _lib.iptr(kv_self),
-                                             _lib.iptr(kv_cross), seg_off.numel() - 1, int(max_len), 4 if f16 else int(l0.gemm_planes),
-                                             int(l0.attn_precision), _lib.bptr(ws), nb, _lib.ptr(outs), _lib.stream()),
+                                             _lib.iptr(kv_cross), seg_off.numel() - 1, int(max_len), planes,
+                                             attn_precision, _lib.bptr(ws), nb, _lib.ptr(outs), ctx.status_ptr(), _lib.stream()),
                    'regtr_cross_encoder_fwd')
         return outs
 

@@ -124,7 +124,7 @@ def main():
         sys.exit(-3)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: a process group at every world size (one code path)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -201,7 +201,7 @@ def main():
         ok = np.logical_and(rot < cfg.get('reg_success_thresh_rot', 10), trans < cfg.get('reg_success_thresh_trans', 0.1))
         logger.info(f'[Metrics] rot_err_deg_final: {rot.mean():.4f}, trans_err_final: {trans.mean():.4f}, reg_success_final: {ok.mean():.4f} '
                     f'({len(ids)} pairs, {timing["pairs"] / timing["elapsed_s"]:.1f} pairs/s on {timing["world"]} GPU(s))')
-    if world > 1:
+    if world > 1 or 'RANK' in os.environ:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

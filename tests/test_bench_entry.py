@@ -66,7 +66,19 @@ def test_parity_check_logic_on_cpu():
     bad = dict(out)
     bad['src_kp_warped'] = [c.clone() for c in out['src_kp_warped']]
     bad['src_kp_warped'][1][:, 0] += 1e-3
-    assert not bench.parity_check(cfg, Model(), pairs, bad, [0, 1])['ok']
+    r = bench.parity_check(cfg, Model(), pairs, bad, [0, 1])
+    assert not r['ok'] and r['reason'] == 'mismatch'
+    # a pose beyond 1e-4 with correspondences inside it: never ok -- diagnosed ('conditioning' only if the pose is the float64 Kabsch of
+    # the product's own correspondences on an ill-conditioned pair; a shifted pose is not)
+    bad = dict(out)
+    bad['pose'] = out['pose'].clone(); bad['pose'][:, 0, 0, 3] += 5e-4
+    r = bench.parity_check(cfg, Model(), pairs, bad, [0, 1])
+    assert not r['ok'] and r['reason'] == 'mismatch' and r['corr_max_abs'] < 1e-5
+    assert len(r['per_pair']) == 2 and r['per_pair'][0]['slot'] == 0
+    assert bench.parity_slots([5, 9, 1, 7, 3, 3, 8, 2, 6, 4], 8) == sorted(set(bench.parity_slots([5, 9, 1, 7, 3, 3, 8, 2, 6, 4], 8)))
+    sl = bench.parity_slots([5, 9, 1, 7, 3, 3, 8, 2, 6, 4], 8)
+    assert len(sl) == 8 and {0, 9, 1, 2} <= set(sl)                 # first, last, largest, smallest
+    assert bench.parity_slots([5, 9], 8) == [0, 1] and bench.parity_slots([4], 8) == [0]
     bad = dict(out)
     bad['tgt_kp'] = [k.clone() for k in out['tgt_kp']]
     bad['tgt_kp'][0][3, 1] += 1e-6

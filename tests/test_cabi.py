@@ -9,8 +9,8 @@ import torch
 from tests.util import ROOT, load_cfg, seeded_sd
 
 
-def _header_symbols():
-    txt = open(os.path.join(ROOT, 'include', 'regtr_hip.h')).read()
+def _header_symbols(name='regtr_hip.h'):
+    txt = open(os.path.join(ROOT, 'include', name)).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
     return sorted(set(re.findall(r'\b(regtr_\w+)\s*\(', txt)))
 
@@ -23,6 +23,42 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/regtr_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == names, 'ctypes signatures and header disagree'
+    # the opt-in experiment entry points live in their own header, outside the ABI version; nothing is exported that neither declares
+    exp = _header_symbols('regtr_hip_experimental.h')
+    assert sorted(_lib.EXPERIMENTAL) == exp and not set(exp) & set(names)
+    for n in exp:
+        assert hasattr(lib, n), n
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r'\bT (regtr_\w+)', out)))
+    assert exported == sorted(names + exp), set(exported) ^ set(names + exp)
+    txt = open(os.path.join(ROOT, 'include', 'regtr_hip.h')).read()
+    assert int(re.search(r'#define REGTR_ABI_VERSION (\d+)', txt).group(1)) == _lib.ABI_VERSION == lib.regtr_abi_version()
+
+
+def test_context_is_thread_local():
+    """The per-forward state (launch device, operand format, status word, timing lists) lives in a thread-local context stack
+    (regtr_amd/context.py), not in module globals: what one host thread sets, another does not see."""
+    import threading
+    from regtr_amd import context, ops
+    seen = {}
+    gate_a, gate_b = threading.Event(), threading.Event()
+
+    def worker():
+        seen['before'] = context.current().f16_pair
+        with ops.f16_pair(False):
+            gate_a.set(); gate_b.wait(5)
+            seen['inside'] = context.current().f16_pair
+    t = threading.Thread(target=worker)
+    with ops.f16_pair(True), context.recording(gather_records=[1]):
+        t.start(); gate_a.wait(5)
+        assert context.current().f16_pair is True and context.current().gather_records == [1]
+        with ops.f16_pair(False):
+            assert context.current().f16_pair is False and context.current().gather_records == [1]      # nested: fields inherited
+        assert context.current().f16_pair is True
+        gate_b.set(); t.join()
+    assert seen == {'before': False, 'inside': False}
+    assert context.current().f16_pair is False and context.current().gather_records is None
 
 
 def test_workspace_size_queries_are_host_only():

@@ -22,13 +22,20 @@ def _worker(rank, world, port, n_pairs, q):
     # stand-in for the per-pair forward: a pose that is a known function of the pair id
     poses = torch.stack([torch.arange(12, dtype=torch.float32) + 100.0 * i for i in mine]) if mine else torch.zeros(0, 12)
     ids = torch.tensor(mine, dtype=torch.int32)
-    all_poses, all_ids = gather_poses(poses, ids)
+    calls = []
+    for name in ('all_gather', 'all_gather_into_tensor', 'all_reduce', 'broadcast', 'gather', 'all_to_all'):
+        def counted(*a, _f=getattr(dist, name), _n=name, **k):
+            calls.append(_n)
+            return _f(*a, **k)
+        setattr(dist, name, counted)
+    all_poses, all_ids = gather_poses(poses, ids, n_pairs)      # ONE all_gather_into_tensor: ragged shards padded to ceil(n / world), ids carry validity
+    assert calls == ['all_gather_into_tensor'], calls                      # ONE collective, no count exchange
     q.put((rank, all_poses.numpy().copy(), all_ids.numpy().copy()))      # by value: torch tensors travel as fds that die with the worker
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_pairs', [7, 8, 1])
+@pytest.mark.parametrize('n_pairs', [7, 8, 1, 0])
 def test_pose_gather_world2(n_pairs):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -39,7 +46,7 @@ def test_pose_gather_world2(n_pairs):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    exp = torch.stack([torch.arange(12, dtype=torch.float32) + 100.0 * i for i in range(n_pairs)])
+    exp = torch.stack([torch.arange(12, dtype=torch.float32) + 100.0 * i for i in range(n_pairs)]) if n_pairs else torch.zeros(0, 12)
     for _, poses, ids in results:
         assert ids.tolist() == list(range(n_pairs))
         assert torch.equal(torch.from_numpy(poses), exp)

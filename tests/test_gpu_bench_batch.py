@@ -86,15 +86,13 @@ def test_f16_pair_operand_range_on_the_bench_workload():
     benchmark workload: every launch that took the format, the largest |A| and |W| it was handed -- InstanceNorm / LayerNorm outputs,
     their gathered kernel-point sums and ReLU'd projections of those; a factor > 50 below the limit with the seeded weights."""
     import bench
-    from regtr_amd import ops
+    from regtr_amd import context
     dev = torch.device('cuda', 0)
     cfg, model, pairs, batch = bench.build_workload('3dmatch', 16, 20000, False, 0, dev, 'fp32')
-    ops.f16_range_log = log = []
-    try:
+    log = []
+    with context.recording(f16_range_log=log):
         out = model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
         torch.cuda.synchronize()
-    finally:
-        ops.f16_range_log = None
     assert torch.isfinite(out['pose']).all()
     assert len(log) >= 20, 'the batched forward should route its tall contractions through the f16 pair format'
     worst_a, worst_w = max(r[3] for r in log), max(r[4] for r in log)

@@ -773,20 +773,16 @@ def test_gemm_f16_pair_vs_fp64(M, N, K, scale):
     lens = [M // 3, M - M // 3 - 7, 7]
     seg = seg_of(lens)
     ref = a.double() @ w.double().t() / div.double()[:, None] + bias.double() + res.double()
-    prev = ops.use_f16_pair
     errs = {}
-    try:
-        for mode in (False, True):
-            ops.use_f16_pair = mode
+    for mode in (False, True):
+        with ops.f16_pair(mode):
             out, st = ops.gemm(a, sw, bias=bias, row_div=div, residual=res, want_stats=(seg, max(lens)))
-            errs[mode] = ((out.double() - ref).abs().max() / ref.abs().max()).item()
-            if mode:
-                o = 0
-                for c, n in enumerate(lens):
-                    blk = ref[o:o + n]; o += n
-                    assert ((st[c, :, 0].double() - blk.mean(0)).abs().max() / ref.abs().max()).item() < 2e-6
-    finally:
-        ops.use_f16_pair = prev
+        errs[mode] = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+        if mode:
+            o = 0
+            for c, n in enumerate(lens):
+                blk = ref[o:o + n]; o += n
+                assert ((st[c, :, 0].double() - blk.mean(0)).abs().max() / ref.abs().max()).item() < 2e-6
     print(f'gemm M {M} N {N} K {K} scale {scale:g}: max rel err bf16x3 {errs[False]:.2e}, f16 pair {errs[True]:.2e}')
     assert errs[True] < 3e-6 and errs[True] < 8 * max(errs[False], 2e-7)
 

@@ -37,8 +37,9 @@ def arm():
         if planes != 3: s_in = s_out = 0
         kw = dict(a_stats=a_stats if s_in else None, a_seg_off=seg if s_in else None, want_stats=(seg, max_len) if s_out else None, planes=planes)
         ops.force_x3_gemm = True; ops.use_stream_gemm = False
-        ops.use_f16_pair = ops.f16_pair_default          # (REGTR_F16_PAIR=0 / 1 arms)
-        run = lambda: ops.gemm(a, sw, **kw)
+        def run():
+            with ops.f16_pair(ops.f16_pair_default):          # (REGTR_F16_PAIR=0 / 1 arms)
+                return ops.gemm(a, sw, **kw)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
