@@ -216,6 +216,17 @@ def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mo
         cfg.update({'kpconv_ref_row_order': True})
     torch.manual_seed(0); np.random.seed(0)
     model = RegTR(cfg).to(dev).eval()
+    # The default nn.Linear init makes the head's last layer so small that every predicted correspondence collapses onto one point
+    # (spread 1.5 cm against 50 cm of key-point spread): the Kabsch covariance is then nearly rank one (s1 / (s2 + s3) 100 - 330 on
+    # these pairs) and R amplifies the last-bit differences between ANY two float32 implementations by that factor -- one pair in eight
+    # lands beyond 1e-4 on the pose with correspondences equal to 8e-7 (profiles/r04_a_bench_default_init.json).  "pose err vs ref" is
+    # meant to measure the kernels, so the benchmark draws that one 3 x 256 matrix from U(-0.5, 0.5) (as oracle/seeded_weights.py does
+    # for the goldens): predictions spread over metres, the Procrustes problem is well conditioned and the 1e-4 bar on R|t means what
+    # it says.  Still random-init weights; the throughput does not depend on their values.
+    with torch.no_grad():
+        last = getattr(model.correspondence_decoder, 'coor_mlp', None)
+        if last is not None:
+            last[4].weight.uniform_(-0.5, 0.5)
     base = rank * 100003 if first_id is None else first_id
     n_gen = n_pairs if not distinct else min(n_pairs, distinct)
     if config == 'modelnet':
@@ -506,7 +517,7 @@ def main():
             'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32 (f16-pair split, 22-bit operands)', 'fp32x3': 'f32 (bf16x3 split, 24-bit operands)'}.get(dtype, dtype), 'data': 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
-                       'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
+                       'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights (head output layer U(-0.5, 0.5): a well-conditioned Procrustes problem)', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
                        'parallelism': f'pair-sharded x{world}, ONE RCCL all_gather_into_tensor of the (pose | id) rows', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
                        'arithmetic': {'fp32': 'float32-grade: exact operand splits on the 16-bit matrix cores (f16 pair, three MFMA terms, where the strip GEMM / attention '
                                               'kernels serve the shape; bf16x3, six terms, elsewhere), float32 accumulation; exact-f32 MFMA in the KPConv gather',

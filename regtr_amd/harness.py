@@ -63,8 +63,23 @@ def read_ply_xyz(fname):
         return np.stack([data['x'], data['y'], data['z']], 1).astype(np.float64)
 
 
-def load_point_cloud(fname):
-    """demo.py:142-153: .pth (torch-saved array), .ply, .bin (KITTI float32 x y z r); returns (N, 3)."""
+def load_point_cloud(fname, cache_dir=None):
+    """demo.py:142-153: .pth (torch-saved array), .ply, .bin (KITTI float32 x y z r); returns (N, 3).
+    cache_dir: `.pth` fragments (a zip + pickle: ~2 ms each to open, 3562 of them in the 3DLoMatch list) are mirrored there once as
+    float32 `.npy` files and read back with np.load (~0.1 ms); a cache entry older than its source is rebuilt."""
+    if cache_dir is not None and fname.endswith('.pth'):
+        cname = os.path.join(cache_dir, os.path.abspath(fname).strip(os.sep).replace(os.sep, '__')[:-4] + '.npy')
+        try:
+            if os.path.getmtime(cname) >= os.path.getmtime(fname):
+                return np.load(cname)
+        except OSError:
+            pass
+        data = np.ascontiguousarray(load_point_cloud(fname), dtype=np.float32)
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = f'{cname}.{os.getpid()}.tmp.npy'
+        np.save(tmp, data)
+        os.replace(tmp, cname)                       # atomic: concurrent loader processes may race for the same entry
+        return data
     if fname.endswith('.pth'):
         data = torch.load(fname, weights_only=False)
         data = data.numpy() if isinstance(data, torch.Tensor) else np.asarray(data)
@@ -82,10 +97,10 @@ class ThreeDMatchPairs:
     """The 3DMatch / 3DLoMatch test pairs (data_loaders/threedmatch.py:20-101, test phase): an info pickle with keys
     rot (3,3), trans (3,1), src, tgt (paths relative to `root`), overlap."""
 
-    def __init__(self, info_fname, root):
+    def __init__(self, info_fname, root, cache_dir=None):
         with open(info_fname, 'rb') as fid:
             self.infos = pickle.load(fid)
-        self.root = root
+        self.root, self.cache_dir = root, cache_dir
 
     def __len__(self):
         return len(self.infos['rot'])
@@ -93,8 +108,8 @@ class ThreeDMatchPairs:
     def __getitem__(self, i):
         src_path, tgt_path = self.infos['src'][i], self.infos['tgt'][i]
         pose = np.concatenate([self.infos['rot'][i], self.infos['trans'][i].reshape(3, 1)], 1).astype(np.float32)
-        return {'src_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, src_path)), dtype=np.float32),
-                'tgt_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, tgt_path)), dtype=np.float32),
+        return {'src_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, src_path), self.cache_dir), dtype=np.float32),
+                'tgt_xyz': np.ascontiguousarray(load_point_cloud(os.path.join(self.root, tgt_path), self.cache_dir), dtype=np.float32),
                 'pose': pose, 'idx': i, 'src_path': src_path, 'tgt_path': tgt_path}
 
 
@@ -212,7 +227,153 @@ class Prefetcher:
             yield b
 
 
+# ------------------------------------------------------------------------------------------------------ process-pool loading
+# The reference feeds its test loop from a torch DataLoader with `--num_workers` processes (test.py:26, data_loaders/__init__.py:11-58),
+# one pair per step.  Here a forward takes 64 pairs in ~27 ms, i.e. the loader has to deliver ~2300 pairs/s = 4600 files/s, and a
+# torch-saved fragment takes ~2 ms to open: one Python thread (Prefetcher) tops out at ~450 pairs/s.  BatchLoader therefore
+#   * runs `workers` loader PROCESSES (fork: they inherit the pair source, never touch the GPU), each assembling WHOLE batches;
+#   * gives every in-flight batch one slab of shared memory, page-locked once in the parent (hipHostRegister), into which the worker
+#     writes the batch's clouds back to back in the forward's own order [src_0 .. src_{B-1}, tgt_0 .. tgt_{B-1}] -- so a batch crosses
+#     PCIe as ONE asynchronous copy on a side stream instead of 128 small ones, and no array is pickled through a pipe;
+#   * hands the consumer per-cloud VIEWS of that one device buffer; the consumer stream waits on the copy's event only.
+_POOL_SOURCE = None          # the pair source of this process's loader workers (set before the fork)
+_POOL_SLABS = None           # name -> numpy view of the shared slabs (inherited by the fork)
+
+
+def _pool_fill(task):
+    """Runs in a loader process: loads the pairs `idxs` and packs them into slab `slab_id`.  -> (b, slab_id, lens [2B], ids, None) or,
+    when the batch does not fit the slab, (b, slab_id, None, ids, arrays) with the clouds pickled back (correct, slower)."""
+    b, idxs, slab_id = task
+    items = [_POOL_SOURCE[i] for i in idxs]
+    clouds = [it['src_xyz'] for it in items] + [it['tgt_xyz'] for it in items]
+    lens = [int(c.shape[0]) for c in clouds]
+    ids = [int(it['idx']) for it in items]
+    slab = _POOL_SLABS[slab_id]
+    if sum(lens) > slab.shape[0]:
+        return b, slab_id, None, ids, [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
+    o = 0
+    for c, n in zip(clouds, lens):
+        slab[o:o + n] = c
+        o += n
+    return b, slab_id, lens, ids, None
+
+
+class BatchLoader:
+    """Iterates `indices` of `pairs` in batches of `batch` like Prefetcher, with `workers` loader processes and one pinned slab + one H2D
+    copy per batch (see above).  Yields {'src_xyz': [...], 'tgt_xyz': [...], 'ids': [...]} with device tensors (CPU tensors for a cpu
+    `device`: the tests' path).  slab_points: capacity of a slab in points (default: 1.5 x batch x 2 x 30k, grown never -- a larger batch
+    comes back pickled)."""
+
+    def __init__(self, pairs, indices, batch, device, workers=4, depth=None, slab_points=None):
+        import multiprocessing as mp
+        global _POOL_SOURCE, _POOL_SLABS
+        self.indices, self.batch, self.device = list(indices), int(batch), device
+        self.n_batches = (len(self.indices) + self.batch - 1) // self.batch
+        self.workers = max(1, int(workers))
+        depth = depth or (self.workers + 2)
+        cap = int(slab_points or 1.5 * self.batch * 2 * 30000)
+        self.cuda = device.type == 'cuda'
+        # shared, page-locked slabs: anonymous shared mappings created BEFORE the fork (torch tensors in shared memory)
+        self.slab_t = [torch.empty((cap, 3), dtype=torch.float32).share_memory_() for _ in range(min(depth, max(self.n_batches, 1)))]
+        self.registered = []
+        if self.cuda:
+            rt = torch.cuda.cudart()
+            for t in self.slab_t:
+                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) == 0:
+                    self.registered.append(t.data_ptr())
+        self.pinned = self.cuda and len(self.registered) == len(self.slab_t)
+        self.stage = None if (self.pinned or not self.cuda) else torch.empty((cap, 3), dtype=torch.float32).pin_memory()
+        _POOL_SOURCE, _POOL_SLABS = pairs, [t.numpy() for t in self.slab_t]
+        self.pool = mp.get_context('fork').Pool(self.workers)
+        _POOL_SOURCE = None
+        self.copy_stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.free = queue.Queue()
+        for sid in range(len(self.slab_t)):
+            self.free.put(sid)
+        self.pending = queue.Queue()                  # AsyncResults in batch order
+        self.out = queue.Queue(maxsize=len(self.slab_t))
+        self.t_dispatch = threading.Thread(target=self._dispatch, daemon=True)
+        self.t_upload = threading.Thread(target=self._upload, daemon=True)
+        self.t_dispatch.start(); self.t_upload.start()
+
+    def _dispatch(self):
+        try:
+            for b in range(self.n_batches):
+                sid = self.free.get()
+                idxs = self.indices[b * self.batch:(b + 1) * self.batch]
+                self.pending.put(self.pool.apply_async(_pool_fill, ((b, idxs, sid),)))
+            self.pending.put(None)
+        except BaseException as e:      # noqa: BLE001
+            self.pending.put(e)
+
+    def _upload(self):
+        try:
+            while True:
+                res = self.pending.get()
+                if res is None:
+                    break
+                if isinstance(res, BaseException):
+                    raise res
+                b, sid, lens, ids, arrays = res.get()
+                if arrays is not None:                      # oversize batch: the clouds came back by value
+                    lens = [int(a.shape[0]) for a in arrays]
+                    host = torch.from_numpy(np.concatenate(arrays))
+                    if self.cuda:
+                        host = host.pin_memory()
+                else:
+                    host = self.slab_t[sid][:sum(lens)]
+                B = len(ids)
+                off = np.concatenate([[0], np.cumsum(lens)])
+                out = {'ids': ids}
+                if self.cuda:
+                    with torch.cuda.stream(self.copy_stream):
+                        if arrays is None and not self.pinned:      # (hipHostRegister unavailable: through one pinned staging buffer)
+                            self.stage[:host.shape[0]].copy_(host)
+                            host = self.stage[:host.shape[0]]
+                        dev = host.to(self.device, non_blocking=True)
+                        ready = torch.cuda.Event()
+                        ready.record(self.copy_stream)
+                    ready.synchronize()                     # the slab (and the staging buffer) may be refilled from here on
+                    out['dev'] = dev
+                else:
+                    dev = host.clone()
+                self.free.put(sid)
+                views = [dev[off[c]:off[c + 1]] for c in range(2 * B)]
+                out['src_xyz'], out['tgt_xyz'] = views[:B], views[B:]
+                self.out.put(out)
+            self.out.put(None)
+        except BaseException as e:      # noqa: BLE001  (surface loader errors in the consumer)
+            self.out.put(e)
+
+    def __iter__(self):
+        try:
+            while True:
+                b = self.out.get()
+                if b is None:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                if self.cuda:
+                    b['dev'].record_stream(torch.cuda.current_stream(self.device))      # allocated on the copy stream, consumed here
+                yield b
+        finally:
+            self.close()
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate(); self.pool.join()
+            self.pool = None
+            if self.registered:
+                rt = torch.cuda.cudart()
+                for p in self.registered:
+                    rt.cudaHostUnregister(p)
+                self.registered = []
+
+
 # ------------------------------------------------------------------------------------------------------ result files
+_POSE_FMT = ('\t'.join(['%.12f'] * 4) + '\n') * 4      # 4 rows, tab-separated, 12 decimals (generic_reg_model.py:279-281)
+
+
 def write_est_log(log_path, benchmark, records, append=False):
     """generic_reg_model.py:260-281: per scene `<log_path>/<benchmark>/<scene>/est.log`, one block per pair:
     "{tgt_idx}\\t{src_idx}\\t-1" then the 4x4 pose, rows tab-separated with 12 decimals.
@@ -232,9 +393,7 @@ def write_est_log(log_path, benchmark, records, append=False):
                 pose = np.asarray(rec['pose'], dtype=np.float64)
                 if pose.shape[0] == 3:
                     pose = np.concatenate([pose, [[0., 0., 0., 1.]]], axis=0)
-                fid.write('{}\t{}\t{}\n'.format(tgt_idx, src_idx, -1))
-                for i in range(4):
-                    fid.write('\t'.join(map('{0:.12f}'.format, pose[i])) + '\n')
+                fid.write('{}\t{}\t{}\n'.format(tgt_idx, src_idx, -1) + _POSE_FMT % tuple(pose.ravel()))
 
 
 def pose_errors(pred, gt):
@@ -247,8 +406,9 @@ def pose_errors(pred, gt):
 
 
 # ------------------------------------------------------------------------------------------------------ the test loop
-def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
-    """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  Returns, on every rank,
+def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_workers=0):
+    """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  num_workers > 0: loader processes + one pinned slab
+    and one H2D copy per batch (BatchLoader); 0: one loader thread (Prefetcher).  Returns, on every rank,
     (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids, timing dict)."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
@@ -258,11 +418,12 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None):
     model.eval()
     poses, ids = [], []
     t0 = time.perf_counter()
+    loader = BatchLoader(pairs, mine, batch, device, workers=num_workers) if num_workers > 0 else Prefetcher(pairs, mine, batch, device)
     with torch.no_grad():
-        for b in Prefetcher(pairs, mine, batch, device):
+        for b in loader:
             out = model({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
             poses.append(out['pose'][-1])                         # (B, 3, 4), stays on the device
-            ids.extend(it['idx'] for it in b['items'])
+            ids.extend(b['ids'] if 'ids' in b else [it['idx'] for it in b['items']])
     pose_t = torch.cat(poses).reshape(-1, 12) if poses else torch.zeros((0, 12), dtype=torch.float32, device=device)
     id_t = torch.tensor(ids, dtype=torch.int32, device=device)
     all_poses, all_ids = gather_poses(pose_t, id_t, n)

@@ -341,6 +341,7 @@ def test_grid_subsample_floor_keys_vs_restatement(mode):
     """key_mode 1 / 2 (the reference PreprocessorGPU's voxel rule floor(p / dl), kpconv.py:213-240) against the restatement: lattice
     clouds with points exactly on voxel faces, negative coordinates, an empty and a one-point cloud; bit-exact barycentres in
     first-appearance order, and a voxel set that differs from the CPU rule's (key_mode 0)."""
+    from oracle import native
     ops = _ops()
     rng = np.random.default_rng(11)
     clouds = [synth_cloud(rng, 6000, lattice=0.00625) - 1.3, np.zeros((0, 3), np.float32), synth_cloud(rng, 1, lattice=0.05),
