@@ -90,21 +90,112 @@ def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
             'tokens_per_cloud_mean': float(np.mean(lens))}
 
 
+def code_version():
+    """{source_sha256, git_commit, lib_sha256}: the kernel sources this tree holds (regtr_amd/build.py: source_hash), the commit the
+    library was built at (regtr_amd/_build_info.json, written by the build where .git exists) and the loaded library's own hash."""
+    import hashlib
+    from regtr_amd import _lib
+    from regtr_amd.build import source_hash
+    v = {'source_sha256': source_hash(), 'git_commit': None, 'git_dirty': None, 'lib_sha256': None}
+    try:
+        info = json.load(open(os.path.join(ROOT, 'regtr_amd', '_build_info.json')))
+        if info.get('source_sha256') == v['source_sha256']:
+            v['git_commit'], v['git_dirty'] = info.get('git_commit'), info.get('git_dirty')
+    except (OSError, ValueError):
+        pass
+    try:
+        v['lib_sha256'] = hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()
+    except OSError:
+        pass
+    return v
+
+
 def pmc_traffic(pairs, points, shuffle, detail):
-    """HBM bytes per KPConv-gather launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    tools/gpu_round.sh and profiles/pmc_traffic.json) -- counters cannot be collected from inside the timed process, so
-    the figure is reported only when the committed profile was taken on this very workload; otherwise null."""
+    """HBM bytes per KPConv-gather launch from profiles/pmc_traffic.json -- written by `python bench.py --collect-pmc` (counters cannot
+    be read from inside the timed process: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this very script).  Reported only
+    when that file was taken on THIS workload and THIS code version (kernel source hash); otherwise null, with the reason."""
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
+        detail['traffic_note'] = 'profiles/pmc_traffic.json absent: run `python bench.py --collect-pmc` on the GPU'
         return None
     if t.get('workload') != {'pairs': pairs, 'points': points, 'shuffle': bool(shuffle)}:
+        detail['traffic_note'] = f"profiles/pmc_traffic.json was taken on another workload ({t.get('workload')})"
+        return None
+    here = code_version()
+    if t.get('code', {}).get('source_sha256') != here['source_sha256']:
+        detail['traffic_note'] = (f"profiles/pmc_traffic.json was taken on other kernel sources (commit {t.get('code', {}).get('git_commit')}): "
+                                  're-run `python bench.py --collect-pmc`')
         return None
     detail['traffic_unit'] = 'HBM bytes per launch (mean over the gather launches of a forward)'
     detail['traffic_source'] = t.get('source')
+    detail['traffic_code'] = t.get('code')
     detail['alg_bytes_per_launch'] = detail['alg_gather_bytes_per_step'] / detail['launches_per_step']
     return t['hbm_bytes_per_launch']
+
+
+def collect_pmc(args):
+    """`python bench.py --collect-pmc`: the counter passes behind `roofline.traffic`, reproducibly.  Two rocprofv3 runs (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, kernel trace only -- MI355X_MICROARCH.md's HBM recipe) over `bench.py --steps 2 --warmup 1` on the same
+    workload flags; per-kernel HBM bytes per launch = 2 x FETCH_SIZE KB (gfx950 tallies 128-byte requests at 64 B) + WRITE_SIZE KB.
+    Writes profiles/pmc_traffic.json (stamped with the code version) and profiles/<tag>_pmc_traffic_kernels.md."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    from collections import defaultdict
+    if not shutil.which('rocprofv3'):
+        sys.exit('bench.py --collect-pmc: rocprofv3 not found')
+    work = tempfile.mkdtemp(prefix='regtr_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
+    inner = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-roofline',
+             '--parity-pairs', '0', '--no-strict-f32', '--points', str(args.points)] + (['--pairs', str(args.pairs)] if args.pairs else []) \
+        + (['--shuffle'] if args.shuffle else [])
+    vals = defaultdict(lambda: defaultdict(list))
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = os.path.join(work, ctr)
+        cmd = ['rocprofv3', '--pmc', ctr, '--kernel-trace', '--output-format', 'csv', '-d', out, '-o', 'p', '--'] + inner
+        r = subprocess.run(cmd, cwd=work, env=dict(os.environ, TMPDIR=work), capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.exit(f'bench.py --collect-pmc: {ctr} pass failed:\n{r.stdout[-1500:]}\n{r.stderr[-1500:]}')
+        for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+            per, names = defaultdict(float), {}
+            for row in csv.DictReader(open(f)):
+                if row['Counter_Name'] == ctr:
+                    per[row['Dispatch_Id']] += float(row['Counter_Value'])
+                    name = re.sub(r'\(anonymous namespace\)::', '', row['Kernel_Name'])
+                    m = re.match(r'(?:void )?([\w:<>, ]+?)\(', name)
+                    names[row['Dispatch_Id']] = (m.group(1) if m else name)[:80]
+            for d, v in per.items():
+                vals[names[d]][ctr].append(v)
+    shutil.rmtree(work, ignore_errors=True)
+    kernels = {}
+    for k, v in vals.items():
+        f, w = v.get('FETCH_SIZE', []), v.get('WRITE_SIZE', [])
+        kernels[k] = {'launches': max(len(f), len(w)), 'fetch_bytes_per_launch': 2 * 1024 * sum(f) / max(len(f), 1),
+                      'write_bytes_per_launch': 1024 * sum(w) / max(len(w), 1)}
+    g = {k: v for k, v in kernels.items() if 'k_kpconv_gather' in k}
+    n = sum(v['launches'] for v in g.values())
+    if n == 0:
+        sys.exit('bench.py --collect-pmc: no KPConv gather launch in the counter output')
+    total = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g.values())
+    code = code_version()
+    pairs = args.pairs if args.pairs else 64
+    res = {'workload': {'pairs': pairs, 'points': args.points, 'shuffle': bool(args.shuffle)}, 'hbm_bytes_per_launch': total / n, 'code': code,
+           'source': ('`python bench.py --collect-pmc`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over '
+                      f'`bench.py --steps 2 --warmup 1`; bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE KB; mean '
+                      f'over {n} gather launches; kernel sources {code["source_sha256"][:12]}, commit {code["git_commit"]}'),
+           'gather_kernels': g}
+    os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+    with open(os.path.join(ROOT, 'profiles', f'{args.pmc_tag}_pmc_traffic_kernels.md'), 'w') as f:
+        f.write(f'# HBM traffic per launch (rocprofv3 PMC, `python bench.py --collect-pmc`), kernel sources {code["source_sha256"][:12]}, commit {code["git_commit"]}\n\n')
+        f.write('| kernel | launches | fetch MB / launch | write MB / launch |\n|---|---|---|---|\n')
+        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['launches'] * (kv[1]['fetch_bytes_per_launch'] + kv[1]['write_bytes_per_launch'])):
+            f.write(f"| {k} | {v['launches']} | {v['fetch_bytes_per_launch'] / 1e6:.1f} | {v['write_bytes_per_launch'] / 1e6:.1f} |\n")
+    print(json.dumps({k: res[k] for k in ('workload', 'hbm_bytes_per_launch', 'code')}))
 
 
 def usable_cores():
@@ -427,10 +518,14 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-strict-f32', action='store_true', help="skip the side measurement of compute_dtype 'fp32x3' on the same workload")
     ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
+    ap.add_argument('--collect-pmc', action='store_true', help='run the rocprofv3 counter passes behind roofline.traffic on this workload and write profiles/pmc_traffic.json (stamped with the code version)')
+    ap.add_argument('--pmc-tag', default='r04', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-only', action='store_true',
                     help='no GPU needed: time only the CPU baseline leg on the synthetic workload and print it (where /root/reference '
                          'exists this times the REAL reference module, kind "reference")')
     args = ap.parse_args()
+    if args.collect_pmc:
+        return collect_pmc(args)
     if args.cpu_baseline_only:
         from regtr_amd.config import load_config
         arch = '3dmatch' if args.config == 'lomatch' else args.config
@@ -548,6 +643,7 @@ def main():
                                                                'bf16': 'plain bf16 (1 MFMA per product)'}[dtype],
                                                    peak_note='dense bf16 / f16 MFMA peak; the split modes issue 6x (bf16x3) / 3x (f16 pair) the algorithmic flops')}
             # the dominant kernel of the configuration leads: KPConv gather (HBM) for 3DMatch-size pairs, attention (MFMA) for ModelNet
+            res['config']['code'] = code_version()
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
         if dtype not in ('fp32', 'fp32x3'):

@@ -29,6 +29,36 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 over the kernel sources and headers (sorted by name): the code version of libregtr_hip.so.  profiles/pmc_traffic.json is
+    stamped with it and bench.py reports the counter traffic only when it matches the sources the loaded library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+                   + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')])
+    for f in files:
+        h.update(os.path.basename(f).encode() + b'\0')
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def write_build_info():
+    """regtr_amd/_build_info.json next to the library: source hash + git commit (the GPU boxes receive a snapshot without .git)."""
+    import json
+    info = {'source_sha256': source_hash(), 'git_commit': None, 'git_dirty': None}
+    try:
+        root = os.path.dirname(HERE)
+        info['git_commit'] = subprocess.check_output(['git', '-C', root, 'rev-parse', 'HEAD'], stderr=subprocess.DEVNULL, text=True).strip()
+        info['git_dirty'] = bool(subprocess.check_output(['git', '-C', root, 'status', '--porcelain', '--', 'regtr_amd', 'include'],
+                                                         stderr=subprocess.DEVNULL, text=True).strip())
+    except (OSError, subprocess.CalledProcessError):
+        pass
+    with open(os.path.join(HERE, '_build_info.json'), 'w') as f:
+        json.dump(info, f, indent=1)
+    return info
+
+
 def build(force=False, verbose=False):
     objdir = os.path.join(HERE, 'build', VARIANT) if VARIANT else os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
@@ -55,6 +85,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+    if not VARIANT and os.path.isdir(os.path.join(os.path.dirname(HERE), '.git')):
+        write_build_info()
     return LIB
 
 

@@ -130,29 +130,46 @@ class SyntheticPairs:
         return {'src_xyz': src, 'tgt_xyz': tgt, 'pose': pose, 'idx': i, 'src_path': sp, 'tgt_path': tp}
 
 
-def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank=0, world=1):
+def _materialize_one(args):
+    root, n, points, overlap, distinct, i = args
+    src = SyntheticPairs(n, points, overlap=overlap)
+    it = src[i % distinct if distinct else i]
+    for rel, arr in zip(_synthetic_paths(src, i), (it['src_xyz'], it['tgt_xyz'])):
+        os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
+        torch.save(arr, os.path.join(root, rel))
+    return i, it['pose']
+
+
+def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank=0, world=1, distinct=0, procs=None):
     """Writes N synthetic pairs in the layout of the 3DMatch test set -- <root>/test/<scene>/cloud_bin_<k>.pth (torch-saved (N,3) float32
     arrays, what data_loaders/threedmatch.py:74-75 torch.load()s) and an info pickle (keys rot, trans, src, tgt, overlap,
     threedmatch.py:34-40) -- so that ThreeDMatchPairs, the loader thread and the est.log writer run exactly as on the real data set.
     Rank r generates and writes pairs r, r + world, ...; the ground-truth poses are exchanged through small per-rank files, so the
-    pickle is complete on every rank.  -> info pickle path"""
+    pickle is complete on every rank.  distinct > 0: only that many different pairs are generated (pair i = pair i % distinct; every pair still
+    gets its own two files, so the loader's work is the full set's) -- set-up time of the end-to-end measurement.  The pairs are generated
+    by `procs` processes (default: the usable cores, at most 16; spawned, so the caller may already hold a GPU).  -> info pickle path"""
     src = SyntheticPairs(n, points, overlap=overlap)
     t0 = time.perf_counter()
     os.makedirs(root, exist_ok=True)
     path = os.path.join(root, f'test_info.rank{rank}.pkl')
     stamp = os.path.join(root, f'complete.rank{rank}.json')           # written last: (n, points, overlap, world) of a finished set
-    want = json.dumps([n, points, overlap, world])
+    want = json.dumps([n, points, overlap, world, distinct])
     if world == 1 and os.path.exists(stamp) and open(stamp).read() == want and os.path.exists(path):
         if logger:
             logger.info(f'{n} synthetic pairs already materialised under {root}')
         return path
     poses = {}
-    for i in range(rank, n, world):
-        it = src[i]
-        poses[i] = it['pose']
-        for rel, arr in zip(_synthetic_paths(src, i), (it['src_xyz'], it['tgt_xyz'])):
-            os.makedirs(os.path.dirname(os.path.join(root, rel)), exist_ok=True)
-            torch.save(arr, os.path.join(root, rel))
+    todo = [(root, n, points, overlap, distinct, i) for i in range(rank, n, world)]
+    procs = procs if procs is not None else max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))
+    if procs > 1 and len(todo) > 4:
+        import multiprocessing as mp
+        with mp.get_context('spawn').Pool(procs) as pool:
+            for i, pose in pool.imap_unordered(_materialize_one, todo, chunksize=max(1, len(todo) // (8 * procs))):
+                poses[i] = pose
+    else:
+        for a in todo:
+            i, pose = _materialize_one(a)
+            poses[i] = pose
     with open(os.path.join(root, f'poses.rank{rank}.pkl'), 'wb') as f:
         pickle.dump(poses, f)
     if world > 1:

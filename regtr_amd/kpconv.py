@@ -344,8 +344,14 @@ class ResnetBottleneckBlock(nn.Module):
         w2 = _prepared(self.unary2._cache, 'w', self.unary2.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
         if ops.block_tail_res_ok(x, st, w2, shortcut):
             return ops.block_tail_res(x, st, w2, shortcut, sc_st, v.seg_post, v.max_post)
-        # IN + LReLU of the convolution output (:727) is folded into unary2's GEMM A-operand load (:730)
-        y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post)
+        # IN + LReLU of the convolution output (:727): folded into unary2's GEMM A-operand load (:730) where the one-shot strip kernel takes
+        # the fold (K <= 64); for the deeper levels (K >= 128) the fold would route the product to the tiled kernel (A staged through
+        # registers, two barriers per k-tile: 246 us against 118 us for the same shape on the row-strip kernel at level 3), so the narrow
+        # conv output is normalised in place first (one pass over [M, K]: 20-35 us) and the row-strip kernel multiplies it
+        if ops.preapply_unary2 and st is not None and x.shape[0] >= ops.PRENORM_MIN_ROWS and (ops.preapply_unary2 >= 2 or x.shape[1] > 64):
+            ops.instnorm_apply(x, v.seg_post, v.max_post, st, lrelu=True, out=x)
+            st = None
+        y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post if st is not None else None)
         # LeakyReLU( IN(unary2) + [IN](shortcut) ) in one pass                                                :741
         return ops.instnorm_apply(y, v.seg_post, v.max_post, y_st, residual=shortcut, res_stats=sc_st, lrelu=True, out=y)
 

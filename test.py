@@ -46,6 +46,7 @@ parser.add_argument('--materialize', type=str, default=None,
                     help='with --synthetic N: first write the N pairs as <DIR>/test/<scene>/cloud_bin_*.pth + an info pickle (the 3DMatch test-set '
                          'layout, data_loaders/threedmatch.py:74-75) and run the DATASET path over them: .pth loads on the worker thread, pinned '
                          'H2D copies, forwards, pose gather, est.log writes -- the end-to-end figure of the harness')
+parser.add_argument('--distinct', type=int, default=0, help='with --materialize: generate only this many different pairs (pair i = pair i %% distinct; one file pair per pair all the same)')
 parser.add_argument('--overlap', type=str, default=None, help="synthetic pairs: 'lomatch' = 10-30 %% overlap (3DLoMatch-like)")
 parser.add_argument('--max_pairs', type=int, default=None)
 parser.add_argument('--cache_dir', type=str, default=None,
@@ -137,7 +138,7 @@ def main():
     # pairs
     if opt.synthetic > 0 and opt.materialize:
         info = harness.materialize_synthetic(opt.materialize, opt.synthetic, overlap=opt.overlap, logger=logger if rank == 0 else None,
-                                             rank=rank, world=world)
+                                             rank=rank, world=world, distinct=opt.distinct)
         pairs = harness.ThreeDMatchPairs(info, opt.materialize, cache_dir=opt.cache_dir)
     elif opt.synthetic > 0:
         pairs = harness.SyntheticPairs(opt.synthetic, points=20000 if cfg.dataset == '3dmatch' else 717, overlap=opt.overlap)
