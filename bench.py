@@ -90,6 +90,49 @@ def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
             'tokens_per_cloud_mean': float(np.mean(lens))}
 
 
+def measure_gemm_roofline(model, batch, reps=3):
+    """Times every dense launch (split GEMM in either format, one-shot strip, block tail, exact-f32) with HIP events on its stream
+    during real forwards and prices each against BOTH rooflines: matrix pipe = 2 M N K x terms issued / 2.5 PFLOP/s (the f16 pair split
+    issues 3 MFMA terms per product, bf16x3 six; the exact-f32 MFMA runs at 157.3 TFLOP/s) and HBM = (4 M K [x passes] + 4 M N +
+    weight bytes) / 8 TB/s; a launch's bound is the larger of the two times.  -> the `roofline_gemm` block of the bench line."""
+    from regtr_amd import context
+    records = []
+    with context.recording(gemm_records=records):
+        for _ in range(reps):
+            model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
+        torch.cuda.synchronize()
+    shapes = {}
+    for e0, e1, m in records:
+        key = (m['route'], m['M'], m['N'], m['K'], m['fold'], m['stats'])
+        d = shapes.setdefault(key, {'t': 0.0, 'n': 0, 'meta': m})
+        d['t'] += e0.elapsed_time(e1) * 1e-3
+        d['n'] += 1
+    rows, tot, tot_bound, by_route = [], 0.0, 0.0, {}
+    for (route, M, N, K, fold, stats), d in shapes.items():
+        m = d['meta']
+        t = d['t'] / d['n']
+        flops = 2.0 * M * N * K
+        t_mfma = (flops * m['terms'] / (MFMA_BF16_PEAK_TFS * 1e12)) if m['terms'] else flops / 157.3e12
+        bytes_ = 4.0 * M * K * m.get('passes', 1) + 4.0 * M * N + m['w_bytes'] * K * N
+        t_hbm = bytes_ / (HBM_PEAK_GBS * 1e9)
+        bound = 'mfma' if t_mfma >= t_hbm else 'hbm'
+        per_step = d['n'] / reps
+        tot += t * per_step; tot_bound += max(t_mfma, t_hbm) * per_step
+        r = by_route.setdefault(route, [0.0, 0])
+        r[0] += t * per_step; r[1] += per_step
+        rows.append({'route': route, 'M': M, 'N': N, 'K': K, 'folded_norm_operand': bool(fold), 'stats_epilogue': bool(stats),
+                     'launches_per_step': per_step, 'us': round(t * 1e6, 1), 'bound': bound, 'frac': round(max(t_mfma, t_hbm) / t, 3),
+                     'TFLOPs_f32_equiv': round(flops / t / 1e12, 1), 'GBs': round(bytes_ / t / 1e9)})
+    rows.sort(key=lambda r: -r['us'] * r['launches_per_step'])
+    return {'what': 'every dense contraction of a forward (KPConv kernel-point contractions, unary / shortcut / projection / FFN / head Linears), '
+                    'event-timed per launch; frac = roofline time (the larger of matrix-pipe and HBM time) / measured time',
+            'ms_per_step': round(tot * 1e3, 3), 'roofline_ms_per_step': round(tot_bound * 1e3, 3), 'frac': round(tot_bound / tot, 3),
+            'launches_per_step': sum(r['launches_per_step'] for r in rows),
+            'by_route_ms': {k: round(v[0] * 1e3, 3) for k, v in sorted(by_route.items(), key=lambda kv: -kv[1][0])},
+            'peaks': {'mfma_16bit_dense_TFLOPs': MFMA_BF16_PEAK_TFS, 'mfma_f32_TFLOPs': 157.3, 'hbm_GBs': HBM_PEAK_GBS},
+            'top_shapes': rows[:14]}
+
+
 def code_version():
     """{source_sha256, git_commit, lib_sha256}: the kernel sources this tree holds (regtr_amd/build.py: source_hash), the commit the
     library was built at (regtr_amd/_build_info.json, written by the build where .git exists) and the loaded library's own hash."""
@@ -646,6 +689,7 @@ def main():
             res['config']['code'] = code_version()
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
+            res['roofline_gemm'] = measure_gemm_roofline(model, fwd_batch)
         if dtype not in ('fp32', 'fp32x3'):
             # reduced-precision error, reported next to the number (parity is gated in fp32): same batch, float32-grade model
             from regtr_amd import RegTR, load_config

@@ -87,9 +87,12 @@ size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_or
  *   2  floor(p * (1 / dl)), reciprocal rounded to float32 -- the same rule as torch's CUDA division by a host scalar evaluates it.
  * 0 and 1 give DIFFERENT voxel sets wherever points sit on voxel faces (3DMatch fragments lie on a lattice: red-kitchen pair
  * 9 977 vs 10 088 level-1 points).  Barycentre arithmetic and the first-appearance row order are the same for every mode
- * (MinkowskiEngine's own output order and summation order are unspecified).  row_order 1 requires key_mode 0. */
+ * (MinkowskiEngine's own output order and summation order are unspecified).  row_order 1 requires key_mode 0.
+ * out_cap: rows of out_xyz (<= 0 or > n_cap: n_cap).  The output size is data dependent and only known on the device; a caller that
+ * allocates less than n_cap rows gets the first out_cap voxels (first-appearance order), out_seg_off SATURATED at out_cap, and detects
+ * the full level by out_seg_off[n_clouds] == out_cap (then repeats with a larger capacity).  row_order 1 needs out_cap = n_cap. */
 int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order, int key_mode,
-                                 float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
+                                 int out_cap, float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream);
 
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds);
 

@@ -1,7 +1,7 @@
 /* regtr_hip_experimental.h -- entry points of libregtr_hip.so that are NOT part of the drop-in boundary (include/regtr_hip.h) and
  * NOT covered by REGTR_ABI_VERSION: kernels that were built, tested and MEASURED SLOWER than the path the product runs (kept so the
  * measurements in DESIGN.md section 8 can be reproduced), and diagnostics.  Nothing in the default forward calls them; they are
- * reachable through opt-in switches of regtr_amd/ops.py only (REGTR_FUSED_KPCONV, REGTR_BLOCK_TAIL_RES, REGTR_F16_GATHER).
+ * reachable through opt-in switches of regtr_amd/ops.py only (REGTR_FUSED_KPCONV, REGTR_BLOCK_TAIL_RES).
  * Signatures here may change or disappear without a version bump. */
 #ifndef REGTR_HIP_EXPERIMENTAL_H
 #define REGTR_HIP_EXPERIMENTAL_H
@@ -11,15 +11,6 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-/* The deep-level gather on the f16 matrix pipe (Cin a multiple of 64, H <= 40): feature rows as f16 pair planes [n][2][Cin]
- * (regtr_f16_pair_planes of the normalised float32 features: x = h0 + h1 / 2048, the same 4 bytes per value), staged in LDS and read back
- * transposed (ds_read_b64_tr_b16) as v_mfma_f32_16x16x32_f16 operands; float32-grade like regtr_kpconv_gather, operands below 65504. */
-int regtr_f16_pair_planes(const float* x, int n, int C, void* planes, void* stream);
-int regtr_kpconv_gather_f16_supported(int Cin, int H, int KP);
-int regtr_kpconv_gather_f16(const float* q_xyz, int nq, int ns, const int* nbr, int H, const void* x_planes, int Cin, const float* s_xyzf,
-                            const float* kernel_points, int KP, float extent, float* wf, float* num, void* stream);
-
 
 /* KPConv.forward (kpconv_blocks.py:269-414) in ONE launch for the level-0 shape -- 32 -> 32 channels, 15 kernel points, rows of at
  * most 40 neighbours (regtr_kpconv_fused_supported): gather, kernel-point correlation, contraction with W [480,32] and the division

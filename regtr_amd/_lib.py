@@ -30,7 +30,7 @@ SIGNATURES = {
     'regtr_grid_subsample_ws_bytes': (_Z, [_I, _I]),
     'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'regtr_grid_subsample_ordered_ws_bytes': (_Z, [_I, _I, _I]),
-    'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
+    'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _I, _I, _P, _P, _P, _Z, _P]),
     'regtr_kdtree_ws_bytes': (_Z, [_I, _I]),
     'regtr_kdtree_query_scratch_bytes': (_Z, [_I]),
     'regtr_kdtree_build': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
@@ -83,9 +83,6 @@ SIGNATURES = {
 
 # include/regtr_hip_experimental.h: measured-slower experiment kernels and diagnostics, outside the ABI version (opt-in switches only)
 EXPERIMENTAL = {
-    'regtr_f16_pair_planes': (_I, [_P, _I, _I, _P, _P]),
-    'regtr_kpconv_gather_f16_supported': (_I, [_I, _I, _I]),
-    'regtr_kpconv_gather_f16': (_I, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _I, _F, _P, _P, _P]),
     'regtr_gemm_x3_strip_occupancy': (_I, [_I, _I, _I]),
     'regtr_kpconv_fused_supported': (_I, [_I, _I, _I, _I]),
     'regtr_kpconv_fused': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _P]),

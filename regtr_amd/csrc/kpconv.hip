@@ -438,195 +438,12 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The same gather on the 16-bit matrix pipe, for the deep levels (Cin a multiple of 64, H <= 40), in the f16 PAIR format of gemm_x3.hip:
-// x = h0 + h1 / 2048 exactly to 22 bits, a product = three f16 MFMA terms, the two low ones in a second accumulator.  The f32 MFMA of
-// the kernel above runs at the vector rate and shares the vector ALU with the influence arithmetic (53-62 % of the SIMD cycles at
-// Cin >= 64); v_mfma_f32_16x16x32_f16 does not.  But every 16-bit MFMA packs its contraction index -- here the NEIGHBOUR -- eight to a
-// lane, so the gathered rows (feature planes written by the producing normalise pass: [row][plane][Cin] f16, the same 4 bytes per value
-// as float32) are staged row-wise in LDS and read back with ds_read_b64_tr_b16: in each 16-lane group lane 4 r + q hands in the address
-// of four 16-bit values (row r, columns 4 q ..) and lane i receives column i of the [4][16] tile (tools/probe/tr_b16_probe.hip).  Two such
-// reads = eight consecutive neighbours of one channel = the B operand; the A operand (influences of the lane's kernel point for eight
-// neighbours) is computed and split by the lane itself.  Neighbour slots 40 .. 63 of the second k-step read a zero chunk.
-// ------------------------------------------------------------------------------------------------------------------
-typedef _Float16 rg_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 rg_f16x2 __attribute__((ext_vector_type(2)));
-typedef short rg_s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-constexpr int GF_ROWS = 40;                            // staged neighbour rows
-constexpr int GF_PASS = 64;                            // channels per pass
-constexpr int GF_ROWB = GF_PASS * 2 + 16;              // bytes per staged row of one plane (+16: rows start 4 banks apart)
-constexpr int GF_IMG = 2 * GF_ROWS * GF_ROWB;          // both planes
-constexpr int GF_WAVE_BYTES = 64 * 16 + GF_IMG + 64;   // nb table (64 float4) | image | zero chunk
-constexpr float GF_SCALE = 2048.f;
-
-__device__ __forceinline__ unsigned gf_pack(float a, float b)
-{
-    rg_f16x2 v;
-    v.x = (_Float16)a; v.y = (_Float16)b;
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ void gf_split2(float a, float b, unsigned& p0, unsigned& p1)
-{
-    p0 = gf_pack(a, b);
-    const rg_f16x2 h = __builtin_bit_cast(rg_f16x2, p0);
-    p1 = gf_pack((a - (float)h.x) * GF_SCALE, (b - (float)h.y) * GF_SCALE);
-}
-typedef __attribute__((address_space(3))) rg_s16x4* gf_lds_s16x4;
-
-__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, 3) k_kpconv_gather_f16(GatherArgs g)      // g.x: feature planes [ns][2][Cin] f16
-{
-    extern __shared__ __align__(16) unsigned char gf_sm[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = rg_lane();
-    const int i16 = lane & 15, kg = lane >> 4;
-    unsigned char* wbase = gf_sm + (size_t)wave * GF_WAVE_BYTES;
-    float4* nb_s = (float4*)wbase;                               // [64]: (rel.x, rel.y, rel.z, feature-row byte offset); 40.. = far away
-    unsigned char* img = wbase + 64 * 16;                        // [plane][row][GF_ROWB]
-    unsigned char* zero = img + GF_IMG;                          // 64 bytes of zeros
-    const int H = g.H, Cin = g.Cin, ns = g.ns, nq = g.nq;
-    const bool kvalid = i16 < g.KP;
-    const int kc = kvalid ? i16 : 0;
-    const float kx = kvalid ? g.kp[3 * kc] : 1e30f, ky = g.kp[3 * kc + 1], kz = g.kp[3 * kc + 2];
-    const float inv_extent = 1.0f / g.extent;
-    const unsigned row_bytes = (unsigned)Cin * 4u;               // two f16 planes
-    const __amdgpu_buffer_rsrc_t x_rs = rg_rsrc(g.x, (unsigned)ns * row_bytes);
-    const __amdgpu_buffer_rsrc_t xyzf_rs = rg_rsrc(g.s_xyzf, (unsigned)ns * 16u);
-    if (lane >= GF_ROWS) nb_s[lane] = make_float4(1e6f, 1e6f, 1e6f, __uint_as_float(RG_OOB));      // slots 40 .. 63: no neighbour
-    if (lane < 16) ((unsigned*)zero)[lane] = 0u;
-    // staging role: row 4 j + kg, 16-byte chunk i16 of a 64-channel pass: chunks 0-7 = plane 0, 8-15 = plane 1
-    const unsigned ld_off = (i16 < 8 ? 0u : (unsigned)Cin * 2u) + (unsigned)(i16 & 7) * 16u;
-    const unsigned st_off0 = (i16 < 8 ? 0u : (unsigned)(GF_ROWS * GF_ROWB)) + (unsigned)(i16 & 7) * 16u + (unsigned)kg * GF_ROWB;
-    // transpose-read role: tile row r = i16 / 4, column chunk q = i16 % 4
-    const int tr_r = i16 >> 2, tr_q = i16 & 3;
-    const unsigned wf_q_bytes = (unsigned)g.KP * (unsigned)Cin * 4u;
-    unsigned st_row[4];                                           // WF row (kernel point 4 kg + r) byte offsets; RG_OOB beyond KP
-#pragma unroll
-    for (int r = 0; r < 4; r++) st_row[r] = (4 * kg + r) < g.KP ? (unsigned)(4 * kg + r) * (unsigned)Cin * 4u + (unsigned)i16 * 4u : RG_OOB;
-
-    const int qpw = g.qpw;
-    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * qpw;
-    if (qbase >= nq) return;
-    const int hl = lane < H ? lane : H - 1;
-    auto load_idx = [&](int q) -> int {
-        const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + hl];
-        return (q < nq && lane < H) ? v : ns;
-    };
-    struct Nb { float rx, ry, rz, f; };
-    auto load_nb = [&](int q, int idx) -> Nb {
-        const bool real = idx < ns;
-        const rg_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xyzf_rs, real ? (unsigned)idx * 16u : RG_OOB, 0, 0);
-        const unsigned qc = (unsigned)(q < nq ? q : nq - 1);
-        const float qx = g.q_xyz[3 * qc], qy = g.q_xyz[3 * qc + 1], qz = g.q_xyz[3 * qc + 2];
-        Nb n;
-        n.rx = (real ? __uint_as_float(r.x) : 1e6f) - qx; n.ry = (real ? __uint_as_float(r.y) : 1e6f) - qy;
-        n.rz = (real ? __uint_as_float(r.z) : 1e6f) - qz; n.f = __uint_as_float(r.w);
-        return n;
-    };
-    int idx_cur = load_idx(qbase);
-    Nb nb_cur = load_nb(qbase, idx_cur);
-    int idx_nxt = load_idx(qbase + 1);
-#pragma unroll 1
-    for (int qq = 0; qq < qpw; qq++) {
-        const int q = qbase + qq;
-        if (q >= nq) return;            // wave-uniform
-        __builtin_amdgcn_wave_barrier();
-        if (lane < GF_ROWS) {
-            const unsigned ro = idx_cur < ns ? (unsigned)idx_cur * row_bytes : RG_OOB;
-            nb_s[lane] = make_float4(nb_cur.rx, nb_cur.ry, nb_cur.rz, __uint_as_float(ro));
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- A operands: influences of kernel point i16 for neighbours 32 s + 8 kg + e, split into the f16 pair
-        rg_f16x8 a_hi[2], a_lo[2];
-#pragma unroll
-        for (int sk = 0; sk < 2; sk++) {
-            unsigned p0[4], p1[4];
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                float w2[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const float4 nb = nb_s[32 * sk + 8 * kg + e + u];
-                    const float dx = nb.x - kx, dy = nb.y - ky, dz = nb.z - kz;
-                    float d2;
-                    {
-#pragma clang fp contract(off)
-                        d2 = (dx * dx + dy * dy) + dz * dz;                                   // kpconv_blocks.py:326-329
-                    }
-                    w2[u] = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);        // :368
-                }
-                gf_split2(w2[0], w2[1], p0[e >> 1], p1[e >> 1]);
-            }
-            a_hi[sk] = __builtin_bit_cast(rg_f16x8, rg_u32x4{p0[0], p0[1], p0[2], p0[3]});
-            a_lo[sk] = __builtin_bit_cast(rg_f16x8, rg_u32x4{p1[0], p1[1], p1[2], p1[3]});
-        }
-        unsigned row_off[10];
-#pragma unroll
-        for (int j = 0; j < 10; j++) row_off[j] = __float_as_uint(nb_s[4 * j + kg].w);
-        const __amdgpu_buffer_rsrc_t wf_rs = rg_rsrc(g.wf + (size_t)q * g.KP * Cin, wf_q_bytes);
-        Nb nb_nxt = nb_cur;
-        int idx_nn = ns;
-        const float f_cur = nb_cur.f;
-#pragma unroll 1
-        for (int c0 = 0; c0 < Cin; c0 += GF_PASS) {
-            // ---- stage the 40 rows' 64 channels (both planes) of this pass: 16 bytes per lane and row group, all loads first
-            rg_u32x4 xv[10];
-#pragma unroll
-            for (int j = 0; j < 10; j++) xv[j] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, row_off[j] + ld_off + (unsigned)c0 * 2u, 0, 0);
-            if (c0 == 0) {   // prefetch for the next queries, queued behind this query's feature gathers
-                nb_nxt = load_nb(q + 1, idx_nxt);
-                idx_nn = load_idx(q + 2);
-            }
-            __builtin_amdgcn_wave_barrier();                      // the previous pass's transpose reads are done
-#pragma unroll
-            for (int j = 0; j < 10; j++) *(rg_u32x4*)(img + st_off0 + (unsigned)(4 * j) * GF_ROWB) = xv[j];
-            __builtin_amdgcn_wave_barrier();
-            // ---- four 16-channel column blocks: D[kernel point][channel] += A[kp][neighbour] B[neighbour][channel]
-#pragma unroll
-            for (int cb = 0; cb < 4; cb++) {
-                floatx4 hi = floatx4{0.f, 0.f, 0.f, 0.f}, lo = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int sk = 0; sk < 2; sk++) {
-                    rg_f16x8 b[2];
-#pragma unroll
-                    for (int p = 0; p < 2; p++) {
-                        const int hA = 32 * sk + 8 * kg + tr_r, hB = hA + 4;
-                        const unsigned char* pa = hA < GF_ROWS ? img + p * (GF_ROWS * GF_ROWB) + hA * GF_ROWB + (cb * 16 + 4 * tr_q) * 2 : zero + tr_q * 8;
-                        const unsigned char* pb = hB < GF_ROWS ? img + p * (GF_ROWS * GF_ROWB) + hB * GF_ROWB + (cb * 16 + 4 * tr_q) * 2 : zero + tr_q * 8;
-                        const rg_s16x4 ra = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_s16x4)pa);
-                        const rg_s16x4 rb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gf_lds_s16x4)pb);
-                        const uint2 ua = __builtin_bit_cast(uint2, ra), ub = __builtin_bit_cast(uint2, rb);
-                        b[p] = __builtin_bit_cast(rg_f16x8, rg_u32x4{ua.x, ua.y, ub.x, ub.y});
-                    }
-                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[sk], b[0], lo, 0, 0, 0);
-                    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[sk], b[0], hi, 0, 0, 0);
-                    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[sk], b[1], lo, 0, 0, 0);
-                }
-                // D: lane (channel i16 of the block, kg) holds kernel points 4 kg + r
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float v = hi[r] + lo[r] * (1.0f / GF_SCALE);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), wf_rs, st_row[r] + (unsigned)(c0 + cb * 16) * 4u, 0, RG_WF_STORE_AUX);
-                }
-            }
-        }
-        const float cnt = (float)__builtin_popcountll(__ballot(f_cur > 0.f));      // lanes = neighbours (kpconv_blocks.py:409-411)
-        if (lane == 0) g.num[q] = fmaxf(cnt, 1.f);
-        idx_cur = idx_nxt; nb_cur = nb_nxt; idx_nxt = idx_nn;
-    }
-}
-
-// float32 rows [n, C] -> f16 pair planes [n][2][C] (the operand format of k_kpconv_gather_f16); one thread per value pair
-__global__ void __launch_bounds__(256) k_f16_pair_planes(const float* __restrict__ x, size_t n_pairs, int C, unsigned* __restrict__ out)
-{
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_pairs) return;
-    const size_t row = e / (size_t)(C / 2);
-    const int cp = (int)(e % (size_t)(C / 2));
-    const float2 v = *(const float2*)(x + row * C + 2 * cp);
-    unsigned p0, p1;
-    gf_split2(v.x, v.y, p0, p1);
-    out[row * C + cp] = p0;                      // plane 0: C f16 = C / 2 words; plane 1 follows
-    out[row * C + C / 2 + cp] = p1;
-}
+// (Rounds 3-4 built this gather on the 16-bit matrix pipe as well -- feature rows as f16 pair planes, staged row-wise in LDS and read
+//  back with ds_read_b64_tr_b16 as v_mfma_f32_16x16x32_f16 operands; round 4 software-pipelined the row loads, swapped the operand roles
+//  for 16-byte stores and cut the contraction to 48 slots.  Correct to 4e-7, a third of the ALU cycles, and still 12-20 % slower than the
+//  kernel above: 40-50 % of a wave's time went into ISSUING the row loads against a full vector-memory pipe -- both kernels ingest the
+//  gathered rows at ~15 B per clock and CU from L2 / Infinity Cache, and that is the limiter at Cin >= 64.  Removed after the
+//  measurement; numbers and phase clocks in profiles/r04_f16_gather_v2.md)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Gather FUSED with the kernel-point contraction, for the level-0 shape (Cin = Cout = 32, 15 kernel points): the weighted features
@@ -957,41 +774,6 @@ int regtr_rowsum_positive(const float* x, int n, int C, const float* stats, cons
 
 // 1 when regtr_kpconv_gather derives the positivity flags from the rows it gathers (flag may then be NULL)
 int regtr_kpconv_gather_computes_flag(int Cin, int H) { return (Cin == 1 || (Cin % 32 == 0 && H <= 64)) ? 1 : 0; }
-
-// x [n, C] float32 -> planes [n][2][C] f16 (4 n C bytes): the f16 pair form of feature rows (x = h0 + h1 / 2048) regtr_kpconv_gather_f16 gathers
-int regtr_f16_pair_planes(const float* x, int n, int C, void* planes, void* stream)
-{
-    if (!x || !planes || n < 0 || C < 2 || C % 2 || ((uintptr_t)x % 8) || ((uintptr_t)planes % 4)) return RG_ERR_ARG;
-    if (n == 0) return RG_OK;
-    const size_t n_pairs = (size_t)n * (C / 2);
-    k_f16_pair_planes<<<(unsigned)((n_pairs + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, n_pairs, C, (unsigned*)planes);
-    RG_RETURN_IF_LAUNCH_FAILED();
-    return RG_OK;
-}
-
-// 1 when regtr_kpconv_gather_f16 serves the shape: Cin a multiple of 64, at most 40 neighbours, at most 16 kernel points
-int regtr_kpconv_gather_f16_supported(int Cin, int H, int KP) { return (Cin >= 64 && Cin % 64 == 0 && H >= 1 && H <= GF_ROWS && KP >= 1 && KP <= KP_PAD) ? 1 : 0; }
-
-// regtr_kpconv_gather for the deep levels on the f16 matrix pipe: x_planes = regtr_f16_pair_planes of the (already normalised) support
-// features, s_xyzf = the (x, y, z, positivity flag) records; everything else as regtr_kpconv_gather.  Float32-grade (22-bit operand
-// pairs, three MFMA terms, float32 accumulation); operands below 65504.
-int regtr_kpconv_gather_f16(const float* q_xyz, int nq, int ns, const int* nbr, int H, const void* x_planes, int Cin, const float* s_xyzf,
-                            const float* kernel_points, int KP, float extent, float* wf, float* num, void* stream)
-{
-    if (!q_xyz || !nbr || !x_planes || !s_xyzf || !kernel_points || !wf || !num || nq < 0 || ns < 1 || !(extent > 0.f)) return RG_ERR_ARG;
-    if (!regtr_kpconv_gather_f16_supported(Cin, H, KP) || (long long)ns * Cin >= (1LL << 29)) return RG_ERR_ARG;
-    if ((((uintptr_t)x_planes | (uintptr_t)s_xyzf) % 16) || ((uintptr_t)wf % 4)) return RG_ERR_ARG;
-    if (nq == 0) return RG_OK;
-    GatherArgs g{q_xyz, nullptr, nbr, (const float*)x_planes, nullptr, s_xyzf, kernel_points, wf, num, nullptr, nullptr,
-                 nq, ns, H, Cin, KP, 0, KP * Cin, extent, 0.f, MG_QPW};
-    int qpw = (int)(((long long)nq + 256 * 12 - 1) / (256 * 12));
-    g.qpw = qpw < 1 ? 1 : (qpw > MG_QPW ? MG_QPW : qpw);
-    const int grid = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * g.qpw));
-    const size_t lds = (size_t)GATHER_WAVES * GF_WAVE_BYTES;
-    k_kpconv_gather_f16<<<grid, GATHER_WAVES * RG_WAVE, lds, (hipStream_t)stream>>>(g);
-    RG_RETURN_IF_LAUNCH_FAILED();
-    return RG_OK;
-}
 
 // wf [nq, KP*Cin] (k-major, channel-minor: matches weights.view(KP*Cin, Cout)), num [nq].
 int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, const int* nbr, int H, const float* x,

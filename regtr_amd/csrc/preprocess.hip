@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(256) k_scatter_members(const int* __restrict__
 __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ xyz, const int* __restrict__ n_ptr,
                                                      const int* __restrict__ slot_of, const int* __restrict__ first,
                                                      const int* __restrict__ cnt, const uint64_t* __restrict__ scan_out,
-                                                     int* __restrict__ members, const int* __restrict__ dest,
+                                                     int* __restrict__ members, const int* __restrict__ dest, int out_cap,
                                                      float* __restrict__ out_xyz)
 {
     const int n = *n_ptr;
@@ -328,6 +328,7 @@ __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ x
     const uint64_t so = scan_out[i];
     const unsigned start = (unsigned)(so & 0xFFFFFFFFu);
     const unsigned j = dest ? (unsigned)dest[so >> 32] : (unsigned)(so >> 32);     // reference row order (parity mode)
+    if (j >= (unsigned)out_cap) return;             // beyond the caller's output capacity: dropped (out_seg_off saturates, see k_out_offsets)
     const int c = cnt[s];
     int* m = members + start;
     for (int a = 1; a < c; a++) {  // insertion sort (lists are a handful of points)
@@ -373,7 +374,7 @@ __global__ void k_umap_order(const uint64_t* __restrict__ vkey, const int* __res
 }
 
 __global__ void k_out_offsets(const int* __restrict__ seg_off, int n_clouds, const uint64_t* __restrict__ scan_in,
-                              const uint64_t* __restrict__ scan_out, int* __restrict__ out_seg_off)
+                              const uint64_t* __restrict__ scan_out, int out_cap, int* __restrict__ out_seg_off)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > n_clouds) return;
@@ -382,7 +383,7 @@ __global__ void k_out_offsets(const int* __restrict__ seg_off, int n_clouds, con
     int v;
     if (i < n) v = (int)(scan_out[i] >> 32);
     else v = n > 0 ? (int)(scan_out[n - 1] >> 32) + (int)(scan_in[n - 1] >> 32) : 0;
-    out_seg_off[b] = v;
+    out_seg_off[b] = v < out_cap ? v : out_cap;      // saturates at the output capacity: a total equal to out_cap tells the caller the level is full
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -875,8 +876,10 @@ size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_or
 size_t regtr_grid_subsample_ws_bytes(int n_cap, int n_clouds) { return regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, 0); }
 
 int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, int row_order, int key_mode,
-                                 float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
+                                 int out_cap, float* out_xyz, int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
 {
+    if (out_cap <= 0 || out_cap > n_cap) out_cap = n_cap;
+    if (row_order == 1 && out_cap != n_cap) return RG_ERR_ARG;      // the container order is replayed over whole clouds
     if (!xyz || !seg_off || !out_xyz || !out_seg_off || n_clouds < 1 || n_cap < 0 || !(dl > 0.f) || row_order < 0 || row_order > 1
         || key_mode < 0 || key_mode > 2 || (row_order == 1 && key_mode != 0))      // the container order belongs to the CPU op's keys
         return RG_ERR_ARG;
@@ -902,12 +905,12 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);
     scan_u64(scan_in, n_ptr, n_cap, bsum, scan_out, st);
     k_scatter_members<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, scan_out, fill, members);
-    k_out_offsets<<<rg_cdiv(n_clouds + 1, 64), 64, 0, st>>>(seg_off, n_clouds, scan_in, scan_out, out_seg_off);
+    k_out_offsets<<<rg_cdiv(n_clouds + 1, 64), 64, 0, st>>>(seg_off, n_clouds, scan_in, scan_out, out_cap, out_seg_off);
     if (row_order == 1) {
         k_rank_keys<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, scan_out, pkey, sb.vkey);
         k_umap_order<<<rg_cdiv(n_clouds, 64), 64, 0, st>>>(sb.vkey, out_seg_off, n_clouds, sb.unext, sb.ubefore, sb.uorder, sb.dest);
     }
-    k_barycentres<<<nb, 256, 0, st>>>(xyz, n_ptr, slot_of, first, cnt, scan_out, members, sb.dest, out_xyz);
+    k_barycentres<<<nb, 256, 0, st>>>(xyz, n_ptr, slot_of, first, cnt, scan_out, members, sb.dest, out_cap, out_xyz);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
@@ -915,7 +918,7 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
 int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int n_cap, float dl, float* out_xyz,
                          int* out_seg_off, void* ws, size_t ws_bytes, void* stream)
 {
-    return regtr_grid_subsample_ordered(xyz, seg_off, n_clouds, n_cap, dl, 0, 0, out_xyz, out_seg_off, ws, ws_bytes, stream);
+    return regtr_grid_subsample_ordered(xyz, seg_off, n_clouds, n_cap, dl, 0, 0, n_cap, out_xyz, out_seg_off, ws, ws_bytes, stream);
 }
 
 size_t regtr_cellgrid_ws_bytes(int ns_cap, int n_clouds)

@@ -161,7 +161,7 @@ def materialize_synthetic(root, n, points=20000, overlap=None, logger=None, rank
     poses = {}
     todo = [(root, n, points, overlap, distinct, i) for i in range(rank, n, world)]
     procs = procs if procs is not None else max(1, min(16, len(os.sched_getaffinity(0)) // max(world, 1)))
-    if procs > 1 and len(todo) > 4:
+    if procs > 1 and len(todo) >= 32:        # (spawned workers import torch: seconds each -- not worth it for a handful of pairs)
         import multiprocessing as mp
         with mp.get_context('spawn').Pool(procs) as pool:
             for i, pose in pool.imap_unordered(_materialize_one, todo, chunksize=max(1, len(todo) // (8 * procs))):
@@ -247,144 +247,207 @@ class Prefetcher:
 # ------------------------------------------------------------------------------------------------------ process-pool loading
 # The reference feeds its test loop from a torch DataLoader with `--num_workers` processes (test.py:26, data_loaders/__init__.py:11-58),
 # one pair per step.  Here a forward takes 64 pairs in ~27 ms, i.e. the loader has to deliver ~2300 pairs/s = 4600 files/s, and a
-# torch-saved fragment takes ~2 ms to open: one Python thread (Prefetcher) tops out at ~450 pairs/s.  BatchLoader therefore
-#   * runs `workers` loader PROCESSES (fork: they inherit the pair source, never touch the GPU), each assembling WHOLE batches;
-#   * gives every in-flight batch one slab of shared memory, page-locked once in the parent (hipHostRegister), into which the worker
-#     writes the batch's clouds back to back in the forward's own order [src_0 .. src_{B-1}, tgt_0 .. tgt_{B-1}] -- so a batch crosses
-#     PCIe as ONE asynchronous copy on a side stream instead of 128 small ones, and no array is pickled through a pipe;
-#   * hands the consumer per-cloud VIEWS of that one device buffer; the consumer stream waits on the copy's event only.
+# torch-saved fragment takes ~2 ms to open: one Python thread (Prefetcher) tops out at ~450-530 pairs/s.  LoaderPool therefore
+#   * runs `workers` loader PROCESSES (forked once, reusable over any number of passes; they inherit the pair source and never touch
+#     the GPU), each assembling WHOLE batches;
+#   * gives every in-flight batch one slab of shared memory (anonymous shared mappings: no page is touched until a worker fills it)
+#     into which the worker writes the batch's clouds back to back in the forward's own order [src_0 .. src_{B-1}, tgt_0 .. tgt_{B-1}]
+#     -- no array is pickled through a pipe;
+#   * moves a filled slab through one of two page-locked staging buffers to the GPU as ONE asynchronous copy on a side stream instead of
+#     128 small ones, and hands the consumer per-cloud VIEWS of that one device buffer; the consumer stream waits on the copy's event.
+# Measured on the 16-core-quota GPU boxes (profiles/r04_*_e2e_harness.txt): more than ~6 loader processes slow the set down (they compete
+# with the launching thread for the quota), hence the default of 4.
 _POOL_SOURCE = None          # the pair source of this process's loader workers (set before the fork)
-_POOL_SLABS = None           # name -> numpy view of the shared slabs (inherited by the fork)
+_POOL_SLABS = None           # slab id -> numpy view of the shared slab (inherited by the fork)
+_PINNED = {}                 # (device, points) -> two page-locked staging buffers, kept for the life of the process
 
 
 def _pool_fill(task):
-    """Runs in a loader process: loads the pairs `idxs` and packs them into slab `slab_id`.  -> (b, slab_id, lens [2B], ids, None) or,
-    when the batch does not fit the slab, (b, slab_id, None, ids, arrays) with the clouds pickled back (correct, slower)."""
-    b, idxs, slab_id = task
+    """Runs in a loader process: loads the pairs `idxs` (one PART of a batch) and packs them into its region [lo, lo + cap) of slab
+    `slab_id` as [src clouds ..., tgt clouds ...].  -> (b, part, lens_src, lens_tgt, ids, None) or, when the part does not fit its
+    region, (b, part, None, None, ids, (src arrays, tgt arrays)) with the clouds pickled back (correct, slower)."""
+    b, part, idxs, slab_id, lo, cap = task
     items = [_POOL_SOURCE[i] for i in idxs]
-    clouds = [it['src_xyz'] for it in items] + [it['tgt_xyz'] for it in items]
-    lens = [int(c.shape[0]) for c in clouds]
+    src, tgt = [it['src_xyz'] for it in items], [it['tgt_xyz'] for it in items]
+    ls, lt = [int(c.shape[0]) for c in src], [int(c.shape[0]) for c in tgt]
     ids = [int(it['idx']) for it in items]
+    if sum(ls) + sum(lt) > cap:
+        return b, part, None, None, ids, ([np.ascontiguousarray(c, dtype=np.float32) for c in src], [np.ascontiguousarray(c, dtype=np.float32) for c in tgt])
     slab = _POOL_SLABS[slab_id]
-    if sum(lens) > slab.shape[0]:
-        return b, slab_id, None, ids, [np.ascontiguousarray(c, dtype=np.float32) for c in clouds]
-    o = 0
-    for c, n in zip(clouds, lens):
+    o = lo
+    for c, n in zip(src + tgt, ls + lt):
         slab[o:o + n] = c
         o += n
-    return b, slab_id, lens, ids, None
+    return b, part, ls, lt, ids, None
 
 
-class BatchLoader:
-    """Iterates `indices` of `pairs` in batches of `batch` like Prefetcher, with `workers` loader processes and one pinned slab + one H2D
-    copy per batch (see above).  Yields {'src_xyz': [...], 'tgt_xyz': [...], 'ids': [...]} with device tensors (CPU tensors for a cpu
-    `device`: the tests' path).  slab_points: capacity of a slab in points (default: 1.5 x batch x 2 x 30k, grown never -- a larger batch
-    comes back pickled)."""
+class LoaderPool:
+    """`workers` forked loader processes + their shared slabs over one pair source; `iterate(indices, batch)` yields batches
+    {'src_xyz': [...], 'tgt_xyz': [...], 'ids': [...]} of device tensors (CPU tensors for a cpu `device`: the tests' path), in order.
+    The pool outlives a pass: create it once (before the GPU is initialised, if possible: forking a process that holds a HIP context
+    copies far more page tables), iterate as often as needed, close() at the end.  slab_points: capacity of a slab in points (default
+    1.25 x max_batch x 2 x 24k; a batch that does not fit comes back pickled -- correct, slower)."""
 
-    def __init__(self, pairs, indices, batch, device, workers=4, depth=None, slab_points=None):
+    def __init__(self, pairs, device, workers=4, max_batch=64, depth=None, slab_points=None):
+        import mmap
         import multiprocessing as mp
         global _POOL_SOURCE, _POOL_SLABS
-        self.indices, self.batch, self.device = list(indices), int(batch), device
-        self.n_batches = (len(self.indices) + self.batch - 1) // self.batch
+        self.device = torch.device(device)
         self.workers = max(1, int(workers))
-        depth = depth or (self.workers + 2)
-        cap = int(slab_points or 1.5 * self.batch * 2 * 30000)
-        self.cuda = device.type == 'cuda'
-        # shared, page-locked slabs: anonymous shared mappings created BEFORE the fork (torch tensors in shared memory)
-        self.slab_t = [torch.empty((cap, 3), dtype=torch.float32).share_memory_() for _ in range(min(depth, max(self.n_batches, 1)))]
-        self.registered = []
-        if self.cuda:
-            rt = torch.cuda.cudart()
-            for t in self.slab_t:
-                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * 4, 0)) == 0:
-                    self.registered.append(t.data_ptr())
-        self.pinned = self.cuda and len(self.registered) == len(self.slab_t)
-        self.stage = None if (self.pinned or not self.cuda) else torch.empty((cap, 3), dtype=torch.float32).pin_memory()
-        _POOL_SOURCE, _POOL_SLABS = pairs, [t.numpy() for t in self.slab_t]
+        self.cuda = self.device.type == 'cuda'
+        self.cap = int(slab_points or 1.25 * max_batch * 2 * 24000)
+        n_slabs = depth or (self.workers + 2)
+        self._maps = [mmap.mmap(-1, self.cap * 12) for _ in range(n_slabs)]           # MAP_SHARED | MAP_ANONYMOUS: inherited by the fork
+        self.slabs = [np.frombuffer(m, dtype=np.float32).reshape(self.cap, 3) for m in self._maps]
+        _POOL_SOURCE, _POOL_SLABS = pairs, self.slabs
         self.pool = mp.get_context('fork').Pool(self.workers)
         _POOL_SOURCE = None
-        self.copy_stream = torch.cuda.Stream(device=device) if self.cuda else None
-        self.free = queue.Queue()
-        for sid in range(len(self.slab_t)):
-            self.free.put(sid)
-        self.pending = queue.Queue()                  # AsyncResults in batch order
-        self.out = queue.Queue(maxsize=len(self.slab_t))
-        self.t_dispatch = threading.Thread(target=self._dispatch, daemon=True)
-        self.t_upload = threading.Thread(target=self._upload, daemon=True)
-        self.t_dispatch.start(); self.t_upload.start()
+        self.copy_stream = None
+        self.last_timing = None
 
-    def _dispatch(self):
-        try:
-            for b in range(self.n_batches):
-                sid = self.free.get()
-                idxs = self.indices[b * self.batch:(b + 1) * self.batch]
-                self.pending.put(self.pool.apply_async(_pool_fill, ((b, idxs, sid),)))
-            self.pending.put(None)
-        except BaseException as e:      # noqa: BLE001
-            self.pending.put(e)
+    def _staging(self):
+        key = (str(self.device), self.cap)
+        if key not in _PINNED:
+            _PINNED[key] = [torch.empty((self.cap, 3), dtype=torch.float32).pin_memory() for _ in range(2)]
+        return _PINNED[key]
 
-    def _upload(self):
-        try:
-            while True:
-                res = self.pending.get()
-                if res is None:
-                    break
-                if isinstance(res, BaseException):
-                    raise res
-                b, sid, lens, ids, arrays = res.get()
-                if arrays is not None:                      # oversize batch: the clouds came back by value
-                    lens = [int(a.shape[0]) for a in arrays]
-                    host = torch.from_numpy(np.concatenate(arrays))
+    def iterate(self, indices, batch):
+        indices, batch = list(indices), int(batch)
+        n_batches = (len(indices) + batch - 1) // batch
+        free, pending, out = queue.Queue(), queue.Queue(), queue.Queue(maxsize=len(self.slabs))
+        for sid in range(len(self.slabs)):
+            free.put(sid)
+        if self.cuda and self.copy_stream is None:
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+        stage = self._staging() if self.cuda else None
+        timing = {'wait_worker_s': 0.0, 'stage_copy_s': 0.0, 'h2d_wait_s': 0.0, 'batches': n_batches}
+        self.last_timing = timing
+
+        # a batch is loaded by up to `workers` processes at once: part p fills region p of the batch's slab (regions of equal capacity;
+        # the copy into the staging buffer compacts them into the forward's order) -- the latency of the FIRST batch is what a short
+        # set pays in full
+        parts = max(1, min(self.workers, 8, batch // 8))
+        region = self.cap // parts
+
+        def dispatch():
+            try:
+                for b in range(n_batches):
+                    sid = free.get()
+                    idxs = indices[b * batch:(b + 1) * batch]
+                    per = (len(idxs) + parts - 1) // parts
+                    tasks = [(b, p, idxs[p * per:(p + 1) * per], sid, p * region, region) for p in range(parts) if idxs[p * per:(p + 1) * per]]
+                    pending.put((sid, [self.pool.apply_async(_pool_fill, (t,)) for t in tasks]))
+                pending.put(None)
+            except BaseException as e:      # noqa: BLE001
+                pending.put(e)
+
+        def upload():
+            try:
+                staged = [None, None]                       # event behind the last H2D copy out of each staging buffer
+                k = 0
+                while True:
+                    res = pending.get()
+                    if res is None:
+                        break
+                    if isinstance(res, BaseException):
+                        raise res
+                    t0 = time.perf_counter()
+                    sid, asyncs = res
+                    done = [a.get() for a in asyncs]                # parts in order
+                    t1 = time.perf_counter()
+                    timing['wait_worker_s'] += t1 - t0
+                    # pieces in the forward's order: every part's src clouds, then every part's tgt clouds
+                    pieces, lens_s, lens_t, ids = [[], []], [], [], []
+                    for (b, part, ls, lt, pid, arrays), t in zip(done, [a_ for a_ in range(len(done))]):
+                        ids += pid
+                        if arrays is not None:              # oversize part: the clouds came back by value
+                            ls, lt = [int(a.shape[0]) for a in arrays[0]], [int(a.shape[0]) for a in arrays[1]]
+                            pieces[0] += [torch.from_numpy(a) for a in arrays[0]]
+                            pieces[1] += [torch.from_numpy(a) for a in arrays[1]]
+                        else:
+                            lo = part * region
+                            pieces[0].append(torch.from_numpy(self.slabs[sid][lo:lo + sum(ls)]))
+                            pieces[1].append(torch.from_numpy(self.slabs[sid][lo + sum(ls):lo + sum(ls) + sum(lt)]))
+                        lens_s += ls; lens_t += lt
+                    lens = lens_s + lens_t
+                    n = sum(lens)
+                    B = len(ids)
+                    off = np.concatenate([[0], np.cumsum(lens)])
+                    item = {'ids': ids}
                     if self.cuda:
-                        host = host.pin_memory()
-                else:
-                    host = self.slab_t[sid][:sum(lens)]
-                B = len(ids)
-                off = np.concatenate([[0], np.cumsum(lens)])
-                out = {'ids': ids}
-                if self.cuda:
-                    with torch.cuda.stream(self.copy_stream):
-                        if arrays is None and not self.pinned:      # (hipHostRegister unavailable: through one pinned staging buffer)
-                            self.stage[:host.shape[0]].copy_(host)
-                            host = self.stage[:host.shape[0]]
-                        dev = host.to(self.device, non_blocking=True)
-                        ready = torch.cuda.Event()
-                        ready.record(self.copy_stream)
-                    ready.synchronize()                     # the slab (and the staging buffer) may be refilled from here on
-                    out['dev'] = dev
-                else:
-                    dev = host.clone()
-                self.free.put(sid)
-                views = [dev[off[c]:off[c + 1]] for c in range(2 * B)]
-                out['src_xyz'], out['tgt_xyz'] = views[:B], views[B:]
-                self.out.put(out)
-            self.out.put(None)
-        except BaseException as e:      # noqa: BLE001  (surface loader errors in the consumer)
-            self.out.put(e)
+                        if n <= self.cap:
+                            if staged[k] is not None:
+                                staged[k].synchronize()     # this staging buffer's previous copy has left
+                            pin = stage[k][:n]
+                        else:
+                            pin = torch.empty((n, 3), dtype=torch.float32).pin_memory()
+                        o = 0
+                        for pc in pieces[0] + pieces[1]:
+                            pin[o:o + pc.shape[0]].copy_(pc)
+                            o += pc.shape[0]
+                        t2 = time.perf_counter()
+                        timing['stage_copy_s'] += t2 - t1
+                        with torch.cuda.stream(self.copy_stream):
+                            dev = pin.to(self.device, non_blocking=True)
+                            ready = torch.cuda.Event()
+                            ready.record(self.copy_stream)
+                        if n <= self.cap:
+                            staged[k] = ready
+                            k ^= 1
+                        else:
+                            ready.synchronize()
+                        item['dev'], item['ready'] = dev, ready
+                    else:
+                        dev = torch.cat(pieces[0] + pieces[1])
+                    free.put(sid)                           # the slab is free as soon as its contents sit in the staging buffer
+                    views = [dev[off[c]:off[c + 1]] for c in range(2 * B)]
+                    item['src_xyz'], item['tgt_xyz'] = views[:B], views[B:]
+                    out.put(item)
+                out.put(None)
+            except BaseException as e:      # noqa: BLE001  (surface loader errors in the consumer)
+                out.put(e)
 
-    def __iter__(self):
-        try:
-            while True:
-                b = self.out.get()
-                if b is None:
-                    return
-                if isinstance(b, BaseException):
-                    raise b
-                if self.cuda:
-                    b['dev'].record_stream(torch.cuda.current_stream(self.device))      # allocated on the copy stream, consumed here
-                yield b
-        finally:
-            self.close()
+        threading.Thread(target=dispatch, daemon=True).start()
+        threading.Thread(target=upload, daemon=True).start()
+        while True:
+            t0 = time.perf_counter()
+            b = out.get()
+            timing['h2d_wait_s'] += time.perf_counter() - t0      # (time the CONSUMER stood waiting for a batch)
+            if b is None:
+                return
+            if isinstance(b, BaseException):
+                raise b
+            if self.cuda:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(b['ready'])
+                b['dev'].record_stream(cur)                 # allocated on the copy stream, consumed here
+            yield b
 
     def close(self):
         if self.pool is not None:
             self.pool.terminate(); self.pool.join()
             self.pool = None
-            if self.registered:
-                rt = torch.cuda.cudart()
-                for p in self.registered:
-                    rt.cudaHostUnregister(p)
-                self.registered = []
+        self.slabs = []
+        for m in self._maps:
+            try:
+                m.close()
+            except BufferError:         # a numpy view still alive somewhere: the mapping goes with the process
+                pass
+        self._maps = []
+
+
+class BatchLoader:
+    """One pass of a LoaderPool created for it (and closed at the end): `for b in BatchLoader(pairs, indices, batch, device, workers)`."""
+
+    def __init__(self, pairs, indices, batch, device, workers=4, depth=None, slab_points=None):
+        self.pool = LoaderPool(pairs, device, workers=workers, max_batch=batch, depth=depth, slab_points=slab_points)
+        self.indices, self.batch = indices, batch
+
+    def __iter__(self):
+        try:
+            yield from self.pool.iterate(self.indices, self.batch)
+        finally:
+            self.pool.close()
 
 
 # ------------------------------------------------------------------------------------------------------ result files
@@ -423,10 +486,11 @@ def pose_errors(pred, gt):
 
 
 # ------------------------------------------------------------------------------------------------------ the test loop
-def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_workers=0):
-    """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  num_workers > 0: loader processes + one pinned slab
-    and one H2D copy per batch (BatchLoader); 0: one loader thread (Prefetcher).  Returns, on every rank,
-    (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids, timing dict)."""
+def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_workers=0, loader_pool=None):
+    """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  loader_pool: a LoaderPool over `pairs` (loader
+    processes forked by the caller, e.g. before the GPU was initialised); else num_workers > 0: a pool forked here for this pass;
+    0: one loader thread (Prefetcher).  Returns, on every rank, (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids,
+    timing dict)."""
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -435,7 +499,10 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_worke
     model.eval()
     poses, ids = [], []
     t0 = time.perf_counter()
-    loader = BatchLoader(pairs, mine, batch, device, workers=num_workers) if num_workers > 0 else Prefetcher(pairs, mine, batch, device)
+    if loader_pool is not None:
+        loader = loader_pool.iterate(mine, batch)
+    else:
+        loader = BatchLoader(pairs, mine, batch, device, workers=num_workers) if num_workers > 0 else Prefetcher(pairs, mine, batch, device)
     with torch.no_grad():
         for b in loader:
             out = model({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
@@ -456,4 +523,5 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_worke
                            "(An f16 pair operand beyond 65504 is not the cause unless cfg.f16_range_check was switched off: RegTR.forward detects that "
                            "and re-runs the forward in fp32x3 arithmetic; compute_dtype: 'fp32x3' avoids the format altogether.)  Check the inputs "
                            'and the checkpoint for non-finite values.')
-    return poses_np, all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world}
+    return poses_np, all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world,
+                                             'loader': getattr(loader_pool, 'last_timing', None)}

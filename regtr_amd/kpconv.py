@@ -66,9 +66,20 @@ class Preprocessor(nn.Module):
         self.cfg = cfg
         self._seg_stage = None      # pinned staging buffer of the cloud offsets (enqueue) and the event behind its last copy
         self._seg_copied = None
+        # Level sizes are data dependent and known only on the device while the pyramid is enqueued, so every level's buffers are sized
+        # from a CAPACITY: level l holds at most capacity[l] x N_0 points.  Each level doubles the voxel size -- a surface loses ~3/4 of
+        # its points per level (3DMatch: 27 % / 7 % / 2 % of N_0), a curve 1/2 -- so the default halves the capacity per level, which
+        # sizes the seven K-column neighbour tables of a 64-pair forward at 1.1 GB instead of 2.7 GB.  A level that FILLS its capacity
+        # saturates on the device (regtr_grid_subsample_ordered's out_cap), is detected at the one size read-back, and the pyramid is
+        # rebuilt at full capacity (N_{l+1} <= N_l always holds) -- from then on this preprocessor stays at full capacity.
+        self.level_capacity = list(cfg.get('kpconv_level_capacity', [1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125]))
+        self.capacity_overflows = 0
 
     def forward(self, pts: List[torch.Tensor]):
-        return self.finish(self.enqueue(pts))
+        meta = self.finish(self.enqueue(pts))
+        if meta is None:                      # a level filled its capacity: once more, at full capacity
+            meta = self.finish(self.enqueue(pts))
+        return meta
 
     def enqueue(self, pts: List[torch.Tensor], level0_event=None):
         """Enqueues the whole pyramid on the current stream without touching the host (default order only; the parity mode's KD-tree
@@ -107,7 +118,7 @@ class Preprocessor(nn.Module):
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
-        lv_points, lv_seg, lv_conv, lv_pool, lv_width = [], [], [], [], []
+        lv_points, lv_seg, lv_conv, lv_pool, lv_width, lv_cap = [], [], [], [], [], []
         cap = n0                                                              # N_{l+1} <= N_l <= N_0
         arch = cfg.architecture
         for block_i, block in enumerate(arch):                               # kpconv.py:328-404
@@ -121,6 +132,8 @@ class Preprocessor(nn.Module):
                 raise NotImplementedError('deformable KPConv is outside the RegTR inference path')
             K = limits[layer]
             strided = 'pool' in block or 'strided' in block
+            ratio = self.level_capacity[layer + 1] if layer + 1 < len(self.level_capacity) else self.level_capacity[-1]
+            cap_next = cap if ref_order else min(cap, max(int(n0 * ratio) + 64, 1))          # (parity mode replays containers over whole clouds)
             dl = 2 * r_normal / cfg.conv_radius                                          # :363
             conv_i = pool_p = pool_seg = pool_i = None
             conv_w = pool_w = K
@@ -131,8 +144,8 @@ class Preprocessor(nn.Module):
                 if layer == 0 and level0_event is not None:
                     level0_event.record()
                 if strided:
-                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, key_mode=key_mode)          # :366 / :213-240
-                    pool_i = grid.query(pool_p, pool_seg, cap, K, order=nb_order)        # :376
+                    pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, key_mode=key_mode, out_cap=cap_next)          # :366 / :213-240
+                    pool_i = grid.query(pool_p, pool_seg, cap_next, K, order=nb_order)   # :376
             else:
                 tree = ops.KdTree(points, seg, cap)
                 if layer_blocks:
@@ -140,9 +153,11 @@ class Preprocessor(nn.Module):
                 if strided:
                     pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, row_order=1)
                     pool_i, pool_w = tree.query(pool_p, pool_seg, cap, r_normal, K)
-            lv_points.append(points); lv_seg.append(seg); lv_conv.append(conv_i); lv_pool.append(pool_i)
+            lv_points.append(points); lv_seg.append(seg); lv_conv.append(conv_i); lv_pool.append(pool_i); lv_cap.append(cap)
             lv_width.append((min(conv_w, K), min(pool_w, K)))                            # kpconv.py:255-258
             points, seg = pool_p, pool_seg
+            if strided:
+                cap = cap_next
             r_normal *= 2
             layer += 1
             layer_blocks = []
@@ -152,7 +167,7 @@ class Preprocessor(nn.Module):
         done = torch.cuda.Event()
         done.record()
         return {'lens0': lens0, 'device': device, 'ref_order': ref_order, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
-                'lv_pool': lv_pool, 'lv_width': lv_width, 'seg_pin': seg_pin, 'done': done}
+                'lv_pool': lv_pool, 'lv_width': lv_width, 'lv_cap': lv_cap, 'seg_pin': seg_pin, 'done': done}
 
     @staticmethod
     def level0_meta(state):
@@ -171,6 +186,16 @@ class Preprocessor(nn.Module):
         state['done'].synchronize()                                                      # host: the sizes have landed
         torch.cuda.current_stream().wait_event(state['done'])                            # stream: the tables are complete
         seg_host = state['seg_pin'].numpy()                                              # (levels, n_clouds + 1)
+        caps = state['lv_cap']
+        full = [l for l in range(1, len(caps)) if caps[l] < caps[l - 1] and int(seg_host[l, -1]) >= caps[l]]
+        if full:        # a subsampled level filled its buffer (saturated on the device): the caller rebuilds at full capacity
+            self.capacity_overflows += 1
+            self.level_capacity = [1.0] * len(self.level_capacity)
+            import logging
+            logging.getLogger('regtr_amd').warning(
+                'KPConv pyramid: level(s) %s filled their capacity (%s of N_0 = %d points); rebuilding at full capacity (cfg.kpconv_level_capacity)',
+                full, [round(caps[l] / max(caps[0], 1), 3) for l in full], caps[0])
+            return None
         data = {'points': [], 'neighbors': [], 'pools': [], 'upsamples': [], 'stack_lengths': [],
                 '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
         want64 = bool(cfg.get('kpconv_meta_int64', False))

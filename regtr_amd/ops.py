@@ -22,18 +22,19 @@ F16_OPERAND_LIMIT = 65504.0 / 2     # f16 pair operands: largest finite f16 is 6
 VOXEL_KEY_MODES = {'origin': 0, 'floor': 1, 'floor_rcp': 2}
 
 
-def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0, key_mode=0):
+def grid_subsample(xyz, seg_off, n_cap, dl, row_order=0, key_mode=0, out_cap=None):
     """xyz (n_cap,3) f32, seg_off (B+1,) i32 [device] -> (out_xyz (n_cap,3) [first out_seg_off[-1] rows live],
     out_seg_off (B+1,) i32 [device]).  Row order: clouds stacked; voxels of a cloud by first appearance (row_order 0) or in
     the reference's libstdc++ unordered_map iteration order (row_order 1, parity mode).  key_mode: 0 the CPU op's voxel rule
     floor((p - origin) / dl), 1 PreprocessorGPU's floor(p / dl), 2 floor(p * (1 / dl)) (include/regtr_hip.h)."""
     L = _lib.lib()
     n_clouds = seg_off.numel() - 1
-    out = torch.empty((max(n_cap, 1), 3), dtype=torch.float32, device=xyz.device)
+    out_cap = int(n_cap if out_cap is None else min(out_cap, n_cap))
+    out = torch.empty((max(out_cap, 1), 3), dtype=torch.float32, device=xyz.device)
     out_off = torch.empty(n_clouds + 1, dtype=torch.int32, device=xyz.device)
     nb = L.regtr_grid_subsample_ordered_ws_bytes(n_cap, n_clouds, int(row_order))
     ws = _ws(nb, xyz.device)
-    check(L.regtr_grid_subsample_ordered(ptr(xyz), iptr(seg_off), n_clouds, n_cap, float(dl), int(row_order), int(key_mode), ptr(out),
+    check(L.regtr_grid_subsample_ordered(ptr(xyz), iptr(seg_off), n_clouds, n_cap, float(dl), int(row_order), int(key_mode), out_cap, ptr(out),
                                          iptr(out_off), bptr(ws), nb, stream()), 'regtr_grid_subsample_ordered')
     return out, out_off
 
@@ -180,6 +181,23 @@ def f16_pair_ok(M, N, K, with_stats=False):
     return v
 
 
+class _GemmTimer:
+    """bench.py's roofline_gemm: HIP events around one dense launch on its stream + what ran (context.recording(gemm_records=[...]))."""
+    __slots__ = ('rec', 'e0', 'meta')
+
+    def __init__(self, rec, **meta):
+        self.rec, self.meta = rec, meta
+        if rec is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def done(self, **more):
+        if self.rec is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.rec.append((self.e0, e1, dict(self.meta, **more)))
+
+
 _x3_shape = {}       # (M, N, K) -> (supported, preferred, workspace bytes, statistics tile rows, launch tile rows): host-side plan queries, memoised
 
 
@@ -214,7 +232,10 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     if (sw is not None and sw.planes is not None and want_stats is not None and bias is None and row_div is None and residual is None
             and not relu and planes == 3 and out is None and stream_ok(M, N, K, a, a_stats)
             and (a_stats is None or a_seg_off is want_stats[0])):
-        return gemm_stream(a, sw, want_stats[0], a_stats=a_stats, a_slope=a_slope, want_stats=True, eps=eps)
+        tm = _GemmTimer(context.current().gemm_records, M=M, N=N, K=K, route='one-shot strip (bf16x3)', terms=6, w_bytes=6, fold=a_stats is not None, stats=True)
+        res = gemm_stream(a, sw, want_stats[0], a_stats=a_stats, a_slope=a_slope, want_stats=True, eps=eps)
+        tm.done()
+        return res
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=a.device)
     ldr = residual.stride(0) if residual is not None else 0
@@ -248,10 +269,13 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
             pl, npl = sw.planes16, 4
             if f16_range_log is not None:      # tests / audits: the largest operand magnitude handed to the f16 pair format (synchronises)
                 f16_range_log.append((M, N, K, float(a.abs().max()) if M else 0.0, float(sw.kn.abs().max())))
+        tm = _GemmTimer(ctx.gemm_records, M=M, N=N, K=K, route='split GEMM (f16 pair)' if npl == 4 else f'split GEMM (bf16 x{npl})',
+                        terms={4: 3, 3: 6, 2: 3, 1: 1}[npl], w_bytes={4: 4, 3: 6, 2: 4, 1: 2}[npl], fold=a_stats is not None, stats=R > 0)
         check(L.regtr_gemm_x3(raw(a), lda, bptr(pl), raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                               raw(residual), ldr, 1 if relu else 0,
                               ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, dptr(partial), iptr(s_off), n_clouds,
                               npl, iptr(ti), ctx.status_ptr(), stream()), 'regtr_gemm_x3')
+        tm.done()
         if R:
             stats = torch.empty((n_clouds, N, 2), dtype=torch.float32, device=a.device)
             check(L.regtr_instnorm_finalize_tiles(dptr(partial), iptr(s_off), n_clouds, N, R, eps, ptr(stats), stream()),
@@ -260,9 +284,11 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     else:
         nb = L.regtr_gemm_f32_ws_bytes(M, N, K)
         ws = _ws(nb, a.device) if nb else None
+        tm = _GemmTimer(ctx.gemm_records, M=M, N=N, K=K, route='exact-f32 MFMA', terms=0, w_bytes=4, fold=a_stats is not None, stats=False)
         check(L.regtr_gemm_f32(raw(a), lda, ptr(b_kn), N, raw(out), ldc, M, N, K, ptr(bias), ptr(row_div),
                                raw(residual), ldr, 1 if relu else 0,
                                ptr(a_stats), iptr(a_seg_off), n_seg, a_slope, bptr(ws), nb, stream()), 'regtr_gemm_f32')
+        tm.done()
     if want_stats is not None:
         return out, instnorm_stats(out, want_stats[0], want_stats[1], eps)
     return out
@@ -341,9 +367,12 @@ def _block_tail(x1, x1_stats, row_div, f, w1_kn, w2_kn, seg_off, max_len, slope,
     ti = tile_segments(seg_off, M, 256)
     y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
     st = torch.empty((2 if K2 else 1, n_clouds, N, 2), dtype=torch.float32, device=x1.device) if want_stats else None
+    tm = _GemmTimer(context.current().gemm_records, M=M, N=N, K=K1 + K2, route='block tail (moments + two-source strip, bf16x3)', terms=6, w_bytes=6,
+                    fold=True, stats=True, passes=2)
     check(L.regtr_block_tail(raw(x1), x1.stride(0), ptr(x1_stats), slope, ptr(row_div), raw(f) if f is not None else None,
                              f.stride(0) if f is not None else 0, ptr(w1_kn), ptr(w2_kn), iptr(seg_off), n_clouds, int(max_len),
                              iptr(ti), M, N, K1, K2, eps, slope, ptr(y), N, bptr(ws), nb, ptr(st), stream()), 'regtr_block_tail')
+    tm.done()
     return (y, st) if want_stats else y
 
 
@@ -504,18 +533,10 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
     if rec is not None:
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
-    # deep levels, packed records, final features: the gather on the f16 matrix pipe (feature rows as f16 pair planes)
-    if (use_f16_gather and xyzf is not None and x_stats is None and nq >= F16_GATHER_MIN_ROWS and ns * Cin < (1 << 29)
-            and L.regtr_kpconv_gather_f16_supported(Cin, H, KP)):
-        planes = torch.empty((ns, Cin), dtype=torch.float32, device=dev)         # [ns][2][Cin] f16 = 4 bytes per value
-        check(L.regtr_f16_pair_planes(ptr(x), ns, Cin, ptr(planes), stream()), 'regtr_f16_pair_planes')
-        check(L.regtr_kpconv_gather_f16(ptr(q_xyz), nq, ns, iptr(nbr), H, ptr(planes), Cin, ptr(xyzf), ptr(kernel_points), KP,
-                                        float(extent), ptr(wf), ptr(num), stream()), 'regtr_kpconv_gather_f16')
-    else:
-      check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
+    check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), Cin, ptr(flag), ptr(xyzf),
                                 ptr(kernel_points), KP, float(extent), ptr(x_stats),
                                 iptr(q_seg_off) if x_stats is not None else None, n_seg, slope, ptr(wf), 0, ptr(num), stream()),
-            'regtr_kpconv_gather')
+          'regtr_kpconv_gather')
     if rec is not None:
         e1.record()
     res = gemm(wf, w_flat, row_div=num, want_stats=want_stats)       # (out, stats) when want_stats is given
@@ -524,10 +545,6 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         rec.append((e0, e1, e2, nq, H, Cin, (res[0] if want_stats is not None else res).shape[1]))
     return res
 
-
-# the deep-level gather (Cin a multiple of 64) on the f16 matrix pipe (csrc/kpconv.hip k_kpconv_gather_f16); A-B runs / tests
-use_f16_gather = os.environ.get('REGTR_F16_GATHER', '0') != '0'
-F16_GATHER_MIN_ROWS = 1
 
 # (bench.py times every KPConv gather launch with HIP events on the launch stream: context.recording(gather_records=[...]))
 

@@ -248,7 +248,10 @@ class RegTR(nn.Module):
             feats0 = torch.ones_like(meta0['points'][0][:, 0:1])
             x, skips = self.kpf_encoder(feats0, meta0, 0, n_l0)
             kpconv_meta = self.preprocessor.finish(state)            # host + main wait for the pyramid's `done` event only
-            self._record_meta(kpconv_meta, main)
+            if kpconv_meta is None:      # a level filled its capacity (rare): the pyramid once more, here, at full capacity -- the level-0
+                kpconv_meta = self.preprocessor(clouds)          # blocks already enqueued read level 0 only, which is never truncated
+            else:
+                self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
         else:

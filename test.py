@@ -49,6 +49,7 @@ parser.add_argument('--materialize', type=str, default=None,
 parser.add_argument('--distinct', type=int, default=0, help='with --materialize: generate only this many different pairs (pair i = pair i %% distinct; one file pair per pair all the same)')
 parser.add_argument('--overlap', type=str, default=None, help="synthetic pairs: 'lomatch' = 10-30 %% overlap (3DLoMatch-like)")
 parser.add_argument('--max_pairs', type=int, default=None)
+parser.add_argument('--no_warmup', action='store_true', help='skip the untimed warm-up forward (weight re-layout, allocator growth) before the timed loop')
 parser.add_argument('--cache_dir', type=str, default=None,
                     help='mirror the torch-saved .pth fragments there once as float32 .npy files (np.load: ~0.1 ms against ~2 ms per fragment)')
 parser.add_argument('--neighbor_order', choices=('nearest', 'index'), default=None,
@@ -155,6 +156,11 @@ def main():
         logger.error('ModelNet h5 loading is not part of the inference hot path here (h5py is not a dependency); use --synthetic N')
         sys.exit(-4)
 
+    # loader processes: forked BEFORE the model exists (a process that holds a HIP context and the weights is slower to fork); they
+    # sit idle until run_test hands them batches -- nothing is read ahead of the timed loop
+    workers = opt.num_workers if opt.num_workers >= 0 else 4
+    pool = harness.LoaderPool(pairs, device, workers=workers, max_batch=opt.batch) if workers > 0 else None
+
     model = RegTR(cfg).to(device)
     if opt.resume:
         state = torch.load(opt.resume, map_location=device, weights_only=False)
@@ -163,9 +169,26 @@ def main():
     else:
         logger.warning('No checkpoint given. Will perform inference using random weights')
 
+    if not opt.no_warmup:
+        # one untimed forward on a synthetic batch of the run's shape: the weights' one-time re-layout (split planes), the first growth
+        # of the caching allocator (~8 GB for 64 pairs) and the tile plans -- what bench.py's warm-up steps absorb.  No dataset file is
+        # touched before the timed loop.
+        from regtr_amd.synthetic import synth_modelnet_pair, synth_pair
+        t_w = time.perf_counter()
+        gen = [(synth_pair(900001 + i, 20000) if cfg.dataset == '3dmatch' else synth_modelnet_pair(900001 + i)) for i in range(2)]
+        wb = {'src_xyz': [torch.from_numpy(gen[i % 2][0]).to(device) for i in range(opt.batch)],
+              'tgt_xyz': [torch.from_numpy(gen[i % 2][1]).to(device) for i in range(opt.batch)]}
+        model.eval()
+        with torch.no_grad():
+            model(wb)
+        torch.cuda.synchronize(device)
+        del wb
+        logger.info(f'warm-up forward ({opt.batch} synthetic pairs, untimed): {time.perf_counter() - t_w:.2f} s')
     t_run = time.perf_counter()
-    workers = opt.num_workers if opt.num_workers >= 0 else min(8, len(os.sched_getaffinity(0)))
-    poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs, num_workers=workers)
+    poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs, loader_pool=pool)
+    if pool is not None:
+        logger.info(f'loader: {timing["loader"]}')
+        pool.close()
     from_files = isinstance(pairs, harness.ThreeDMatchPairs)
     if rank == 0:
         recs, gts = [], []

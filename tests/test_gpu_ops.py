@@ -441,52 +441,6 @@ def test_fused_instnorm_paths_vs_oracle():
     assert (out2.cpu() - ref2).abs().max() < 3e-5 * max(1.0, ref2.abs().max().item())
 
 
-@pytest.mark.parametrize('C2,H', [(64, 40), (128, 40), (256, 40), (64, 33), (128, 21)])
-def test_kpconv_gather_f16_vs_oracle(C2, H):
-    """regtr_kpconv_gather_f16 (deep-level gather on the f16 matrix pipe: feature rows as f16 pair planes staged in LDS, transposed reads,
-    three f16 MFMA terms) against the oracle KPConv and against the exact-f32 matrix-core gather on the same normalised features and
-    (x, y, z, flag) records: two clouds, shadow neighbours (rows narrower than H), negative-sum supports."""
-    from oracle import native, regtr_ref
-    from regtr_amd.kernel_points import K015_CENTER
-    ops = _ops()
-    rng = np.random.default_rng(C2 + H)
-    clouds = [synth_cloud(rng, 900), synth_cloud(rng, 1400) + 7.0]
-    s = np.concatenate(clouds); lens = np.array([900, 1400], np.int32)
-    q, ql = native.grid_subsample(s, lens, 0.08)
-    r = 0.15
-    idx, _, _ = native.radius_neighbors(q, s, ql, lens, r, H)
-    L = torch.from_numpy(lens.astype(np.int64))
-    y2 = (rng.standard_normal((len(s), C2)) * rng.uniform(0.2, 3, C2) + rng.uniform(-2, 2, C2)).astype(np.float32)
-    w3 = (rng.standard_normal((15, C2, 64)) / 30).astype(np.float32)
-    kp = (K015_CENTER * r).astype(np.float32)
-    x2_ref = torch.nn.functional.leaky_relu(regtr_ref.instance_norm(torch.from_numpy(y2), L), 0.1)
-    ref3 = regtr_ref.kpconv(torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64)), x2_ref,
-                            torch.from_numpy(w3), torch.from_numpy(kp), 0.12)
-    yd = to_dev(y2)
-    st3 = ops.instnorm_stats(yd, seg_of(lens), int(lens.max()))
-    xyzf = torch.full((len(s), 4), -1.0, device='cuda')
-    ops.instnorm_apply(yd, seg_of(lens), int(lens.max()), st3, lrelu=True, out=yd, row_xyz=to_dev(s), row_positive=xyzf)
-    args = (to_dev(q), to_dev(s), to_dev(idx), yd, to_dev(w3.reshape(15 * C2, 64)), to_dev(kp), 0.12)
-    prev = ops.use_f16_gather
-    try:
-        ops.use_f16_gather = False
-        plain = ops.kpconv(*args, xyzf=xyzf)
-        ops.use_f16_gather = True
-        assert _lib_supported_f16_gather(C2, H)
-        out = ops.kpconv(*args, xyzf=xyzf)
-    finally:
-        ops.use_f16_gather = prev
-    e_ref = (out.cpu() - ref3).abs().max().item() / max(1.0, ref3.abs().max().item())
-    e_plain = (out - plain).abs().max().item() / max(1.0, plain.abs().max().item())
-    print(f'f16 gather Cin {C2} H {H}: vs oracle {e_ref:.2e}, vs exact-f32 gather {e_plain:.2e}')
-    assert e_ref < 3e-5 and e_plain < 5e-6
-
-
-def _lib_supported_f16_gather(C, H):
-    from regtr_amd import _lib
-    return bool(_lib.lib().regtr_kpconv_gather_f16_supported(C, H, 15))
-
-
 @pytest.mark.parametrize('nq_take', [1, 3])
 def test_kpconv_fused_vs_two_kernel_path(nq_take):
     """regtr_kpconv_fused (level-0 shape: 32 -> 32 channels, weighted features kept in LDS) against gather + contraction, same inputs:
