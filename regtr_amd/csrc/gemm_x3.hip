@@ -1059,6 +1059,9 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     }
 }
 
+// (Round 4 built an A-RESIDENT strip kernel for the short-K products -- A fragments kept in registers for a whole range of columns, weight
+//  planes through an eight-slot LDS ring, one wave per SIMD -- and removed it after measurement: 107-163 us against 92-127 us for k_gemm_x3d on
+//  the K = 256 cross-encoder shapes; phase clocks and the reading in profiles/r04_gemm_ares.md.)
 __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -503,9 +503,12 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_worke
         loader = loader_pool.iterate(mine, batch)
     else:
         loader = BatchLoader(pairs, mine, batch, device, workers=num_workers) if num_workers > 0 else Prefetcher(pairs, mine, batch, device)
+    fwd_ms = []
     with torch.no_grad():
         for b in loader:
+            t_f = time.perf_counter()
             out = model({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
+            fwd_ms.append(round((time.perf_counter() - t_f) * 1e3, 1))
             poses.append(out['pose'][-1])                         # (B, 3, 4), stays on the device
             ids.extend(b['ids'] if 'ids' in b else [it['idx'] for it in b['items']])
     pose_t = torch.cat(poses).reshape(-1, 12) if poses else torch.zeros((0, 12), dtype=torch.float32, device=device)
@@ -524,4 +527,4 @@ def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_worke
                            "and re-runs the forward in fp32x3 arithmetic; compute_dtype: 'fp32x3' avoids the format altogether.)  Check the inputs "
                            'and the checkpoint for non-finite values.')
     return poses_np, all_ids.cpu().numpy(), {'elapsed_s': elapsed, 'pairs': n, 'world': world,
-                                             'loader': getattr(loader_pool, 'last_timing', None)}
+                                             'loader': getattr(loader_pool, 'last_timing', None), 'forward_ms': fwd_ms}

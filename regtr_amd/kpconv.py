@@ -373,7 +373,7 @@ class ResnetBottleneckBlock(nn.Module):
         # the fold (K <= 64); for the deeper levels (K >= 128) the fold would route the product to the tiled kernel (A staged through
         # registers, two barriers per k-tile: 246 us against 118 us for the same shape on the row-strip kernel at level 3), so the narrow
         # conv output is normalised in place first (one pass over [M, K]: 20-35 us) and the row-strip kernel multiplies it
-        if ops.preapply_unary2 and st is not None and x.shape[0] >= ops.PRENORM_MIN_ROWS and (ops.preapply_unary2 >= 2 or x.shape[1] > 64):
+        if ops.preapply_unary2 and st is not None and x.shape[0] >= ops.PREAPPLY_MIN_ROWS and (ops.preapply_unary2 >= 2 or x.shape[1] > 64):
             ops.instnorm_apply(x, v.seg_post, v.max_post, st, lrelu=True, out=x)
             st = None
         y, y_st = self.unary2.linear(x, v.seg_post, v.max_post, a_stats=st, a_seg_off=v.seg_post if st is not None else None)

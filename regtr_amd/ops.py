@@ -439,6 +439,7 @@ use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
 # unary2's folded InstanceNorm + LeakyReLU operand applied by a separate in-place pass instead (kpconv.py ResnetBottleneckBlock): 1 = where the
 # fold would route to the tiled kernel (K > 64), 2 = everywhere, 0 = never (A-B runs)
 preapply_unary2 = int(os.environ.get('REGTR_PREAPPLY_UNARY2', '1'))
+PREAPPLY_MIN_ROWS = 8192        # (a pair or two per forward is launch-bound: the fold saves the extra launch there)
 # the six cross-encoder layers enqueued by one C call (regtr_cross_encoder_fwd) instead of 72 op calls; A-B runs / tests: '0'
 use_one_call_cross_encoder = os.environ.get('REGTR_ONE_CALL_XENC', '1') != '0'
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel

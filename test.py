@@ -49,6 +49,8 @@ parser.add_argument('--materialize', type=str, default=None,
 parser.add_argument('--distinct', type=int, default=0, help='with --materialize: generate only this many different pairs (pair i = pair i %% distinct; one file pair per pair all the same)')
 parser.add_argument('--overlap', type=str, default=None, help="synthetic pairs: 'lomatch' = 10-30 %% overlap (3DLoMatch-like)")
 parser.add_argument('--max_pairs', type=int, default=None)
+parser.add_argument('--warmup_points', type=int, default=24000, help='points per cloud of the warm-up batch (larger than the data so that later batches fit the allocator\'s blocks)')
+parser.add_argument('--alloc_conf', type=str, default='roundup_power2_divisions:8', help='torch caching-allocator settings for the run ("" = leave the defaults)')
 parser.add_argument('--no_warmup', action='store_true', help='skip the untimed warm-up forward (weight re-layout, allocator growth) before the timed loop')
 parser.add_argument('--cache_dir', type=str, default=None,
                     help='mirror the torch-saved .pth fragments there once as float32 .npy files (np.load: ~0.1 ms against ~2 ms per fragment)')
@@ -130,6 +132,11 @@ def main():
         sys.exit(-3)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    if opt.alloc_conf:
+        # one pass over a data set presents a new tensor size to the caching allocator at almost every forward; with its default exact-size
+        # blocks that means hipMalloc calls (10-70 ms each: profiles/r04_f_e2e_forward_ms.txt) long after the warm-up.  Rounding request
+        # sizes up to 1/8-octave steps makes blocks interchangeable between batches (at most 12.5 % more memory)
+        torch.cuda.memory._set_allocator_settings(opt.alloc_conf)
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: a process group at every world size (one code path)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -175,7 +182,7 @@ def main():
         # touched before the timed loop.
         from regtr_amd.synthetic import synth_modelnet_pair, synth_pair
         t_w = time.perf_counter()
-        gen = [(synth_pair(900001 + i, 20000) if cfg.dataset == '3dmatch' else synth_modelnet_pair(900001 + i)) for i in range(2)]
+        gen = [(synth_pair(900001 + i, opt.warmup_points) if cfg.dataset == '3dmatch' else synth_modelnet_pair(900001 + i)) for i in range(2)]
         wb = {'src_xyz': [torch.from_numpy(gen[i % 2][0]).to(device) for i in range(opt.batch)],
               'tgt_xyz': [torch.from_numpy(gen[i % 2][1]).to(device) for i in range(opt.batch)]}
         model.eval()
@@ -187,7 +194,7 @@ def main():
     t_run = time.perf_counter()
     poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs, loader_pool=pool)
     if pool is not None:
-        logger.info(f'loader: {timing["loader"]}')
+        logger.info(f'loader: {timing["loader"]}; forward ms (host clock, incl. the end-of-forward status wait): {timing["forward_ms"]}')
         pool.close()
     from_files = isinstance(pairs, harness.ThreeDMatchPairs)
     if rank == 0:
