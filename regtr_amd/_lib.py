@@ -112,7 +112,11 @@ def _load():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -m regtr_amd.build` '
                                '(hipcc --offload-arch=gfx950). There is no CPU fallback.')
-        _lib = ctypes.CDLL(LIB_PATH)
+        # PyDLL: the calls keep the GIL.  Every entry point only ENQUEUES work (microseconds); releasing the GIL around ~280 such calls per
+        # forward makes the launching thread re-acquire it 280 times, and with any other busy Python thread in the process (the loader's
+        # upload thread, a second model) each re-acquisition can wait a full switch interval (5 ms): 50-100 ms stalls per forward were
+        # measured that way (profiles/r04_e2e_harness.txt)
+        _lib = ctypes.PyDLL(LIB_PATH)
         for name, (res, args) in list(SIGNATURES.items()) + list(EXPERIMENTAL.items()):
             fn = getattr(_lib, name)
             fn.restype = res

@@ -22,6 +22,27 @@ import torch
 from .distributed import gather_poses, shard_pairs
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask capped by a cgroup CPU quota (os.cpu_count() reports the machine's
+    cores even inside a quota-limited container; thread teams larger than the quota spin against each other until the kernel throttles
+    the whole process)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 # ------------------------------------------------------------------------------------------------------ point cloud files
 def read_ply_xyz(fname):
     """Minimal PLY reader (ascii / binary_little_endian, vertex x y z as float or double) -- stands in for
@@ -304,6 +325,8 @@ class LoaderPool:
         _POOL_SOURCE = None
         self.copy_stream = None
         self.last_timing = None
+        if self.cuda:
+            self._staging()                  # (page-locking 2 x cap x 12 bytes takes tens of ms: not inside the first pass)
 
     def _staging(self):
         key = (str(self.device), self.cap)
@@ -319,6 +342,9 @@ class LoaderPool:
             free.put(sid)
         if self.cuda and self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream(device=self.device)
+        import sys
+        if sys.getswitchinterval() > 0.0005:
+            sys.setswitchinterval(0.0005)    # the launching thread shares the interpreter with the two loader threads below: short GIL hand-offs
         stage = self._staging() if self.cuda else None
         timing = {'wait_worker_s': 0.0, 'stage_copy_s': 0.0, 'h2d_wait_s': 0.0, 'batches': n_batches}
         self.last_timing = timing
@@ -381,9 +407,13 @@ class LoaderPool:
                             pin = stage[k][:n]
                         else:
                             pin = torch.empty((n, 3), dtype=torch.float32).pin_memory()
+                        # plain memcpy (numpy): a torch copy_ of this size wakes the whole intra-op thread team -- on a many-core host
+                        # under a cgroup CPU quota the spinning team exhausts the quota and the kernel throttles EVERY thread of the
+                        # process for the rest of the 100 ms period (40-70 ms stalls of the launching thread were measured that way)
+                        pin_np = pin.numpy()
                         o = 0
                         for pc in pieces[0] + pieces[1]:
-                            pin[o:o + pc.shape[0]].copy_(pc)
+                            np.copyto(pin_np[o:o + pc.shape[0]], pc.numpy())
                             o += pc.shape[0]
                         t2 = time.perf_counter()
                         timing['stage_copy_s'] += t2 - t1

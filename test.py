@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')      # idle OpenMP workers must not spin against a cgroup CPU quota
+
 import numpy as np
 import torch
 
@@ -50,7 +52,8 @@ parser.add_argument('--distinct', type=int, default=0, help='with --materialize:
 parser.add_argument('--overlap', type=str, default=None, help="synthetic pairs: 'lomatch' = 10-30 %% overlap (3DLoMatch-like)")
 parser.add_argument('--max_pairs', type=int, default=None)
 parser.add_argument('--warmup_points', type=int, default=24000, help='points per cloud of the warm-up batch (larger than the data so that later batches fit the allocator\'s blocks)')
-parser.add_argument('--alloc_conf', type=str, default='roundup_power2_divisions:8', help='torch caching-allocator settings for the run ("" = leave the defaults)')
+parser.add_argument('--alloc_conf', type=str, default='', help='torch caching-allocator settings for the run (e.g. roundup_power2_divisions:8)')
+parser.add_argument('--reserve_gb', type=float, default=0, help='GiB reserved once and returned to the caching allocator\'s pool before the run (default 0 = off; measured: no effect on the forward-time spikes, which were GIL hand-offs, not hipMalloc)')
 parser.add_argument('--no_warmup', action='store_true', help='skip the untimed warm-up forward (weight re-layout, allocator growth) before the timed loop')
 parser.add_argument('--cache_dir', type=str, default=None,
                     help='mirror the torch-saved .pth fragments there once as float32 .npy files (np.load: ~0.1 ms against ~2 ms per fragment)')
@@ -112,6 +115,9 @@ def main():
 
     from regtr_amd import RegTR, load_config
     from regtr_amd import harness
+    # torch sizes its intra-op thread team from os.cpu_count(); inside a CPU-quota container that is far more threads than cores it may
+    # use, and the oversubscribed team gets the whole process throttled (the host work here is launch issue, not CPU tensor math)
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), harness.usable_cores() // 2, 8)))
     cfg = load_config(opt.config)
     if opt.preprocessor:
         cfg.update({'kpconv_neighbor_order': 'index' if opt.preprocessor == 'gpu' else 'nearest',
@@ -133,10 +139,13 @@ def main():
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     if opt.alloc_conf:
-        # one pass over a data set presents a new tensor size to the caching allocator at almost every forward; with its default exact-size
-        # blocks that means hipMalloc calls (10-70 ms each: profiles/r04_f_e2e_forward_ms.txt) long after the warm-up.  Rounding request
-        # sizes up to 1/8-octave steps makes blocks interchangeable between batches (at most 12.5 % more memory)
         torch.cuda.memory._set_allocator_settings(opt.alloc_conf)
+    reserve_gb = max(opt.reserve_gb, 0.0)
+    if reserve_gb > 0:
+        # optional: one large block reserved up front and handed back to torch's caching allocator, so that later requests are carved out
+        # of it instead of reaching hipMalloc (every level size of every batch is data dependent)
+        torch.empty(int(reserve_gb * 2**30), dtype=torch.uint8, device=device)
+        logger.info(f'allocator pool pre-sized with a {reserve_gb:.0f} GiB block')
     if world > 1 or 'RANK' in os.environ:      # under torch.distributed.run: a process group at every world size (one code path)
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
