@@ -37,48 +37,54 @@ def read_trajectory_info(filename, dim=6):
 
 
 def mat2quat(M):
-    """Rotation matrix -> quaternion (w, x, y, z), w >= 0: eigenvector of the 4x4 K matrix for its largest eigenvalue
-    (Bar-Itzhack), the method and sign convention of nibabel.quaternions.mat2quat."""
-    Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = np.asarray(M, dtype=np.float64).flat
-    K = np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
-                  [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
-                  [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
-                  [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
-    vals, vecs = np.linalg.eigh(K)
-    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
-    return -q if q[0] < 0 else q
+    """Rotation matrices (..., 3, 3) -> quaternions (..., 4) as (w, x, y, z) with w >= 0: eigenvector of the 4x4 K matrix for its largest
+    eigenvalue (Bar-Itzhack), the method and sign convention of nibabel.quaternions.mat2quat -- for a whole stack at once (one batched
+    symmetric eigen-decomposition; K is handed over as its lower triangle, which is all eigh reads)."""
+    M = np.asarray(M, dtype=np.float64)
+    lead = M.shape[:-2]
+    R = M.reshape(-1, 3, 3)
+    K = np.zeros((R.shape[0], 4, 4))
+    K[:, 0, 0] = R[:, 0, 0] - R[:, 1, 1] - R[:, 2, 2]
+    K[:, 1, 0] = R[:, 1, 0] + R[:, 0, 1]; K[:, 1, 1] = R[:, 1, 1] - R[:, 0, 0] - R[:, 2, 2]
+    K[:, 2, 0] = R[:, 2, 0] + R[:, 0, 2]; K[:, 2, 1] = R[:, 2, 1] + R[:, 1, 2]; K[:, 2, 2] = R[:, 2, 2] - R[:, 0, 0] - R[:, 1, 1]
+    K[:, 3, 0] = R[:, 1, 2] - R[:, 2, 1]; K[:, 3, 1] = R[:, 2, 0] - R[:, 0, 2]; K[:, 3, 2] = R[:, 0, 1] - R[:, 1, 0]
+    K[:, 3, 3] = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    vals, vecs = np.linalg.eigh(K / 3.0)
+    q = np.take_along_axis(vecs, np.argmax(vals, axis=1)[:, None, None], axis=2)[:, [3, 0, 1, 2], 0]
+    q = np.where(q[:, :1] < 0, -q, q)
+    return q.reshape(lead + (4,))
 
 
 def transformation_error(trans, info):
-    """RMSE proxy of the Redwood protocol: e^T I e / I[0,0] with e = (t, q_xyz)   (:60-81)."""
-    er = np.concatenate([trans[:3, 3], mat2quat(trans[:3, :3])[1:]])
-    return float(er @ info @ er / info[0, 0])
+    """RMSE proxy of the Redwood protocol, e^T I e / I[0,0] with e = (t, q_xyz)   (:60-81), for stacks (n, 4, 4) / (n, 6, 6) or single matrices."""
+    trans, info = np.asarray(trans, np.float64), np.asarray(info, np.float64)
+    single = trans.ndim == 2
+    T, I = (trans[None], info[None]) if single else (trans, info)
+    e = np.concatenate([T[:, :3, 3], mat2quat(T[:, :3, :3])[:, 1:]], axis=1)
+    p = np.einsum('ni,nij,nj->n', e, I, e) / I[:, 0, 0]
+    return float(p[0]) if single else p
 
 
 def evaluate_registration(num_fragment, result, result_pairs, gt_pairs, gt, gt_info, err2=0.2):
-    """(:223-282) -> precision, recall, flags (0 good / 1 bad / 2 not in gt), per-pair errors."""
-    err2 = err2 ** 2
-    gt_mask = np.zeros((num_fragment, num_fragment), dtype=np.int64)
-    for idx in range(gt_pairs.shape[0]):
-        i, j = int(gt_pairs[idx, 0]), int(gt_pairs[idx, 1])
-        if j - i > 1:                      # only non-consecutive pairs are tested
-            gt_mask[i, j] = idx
-    n_gt = int(np.sum(gt_mask > 0))
-    errors = np.full(result_pairs.shape[0], np.nan)
-    flags, good, n_res = [], 0, 0
-    for idx in range(result_pairs.shape[0]):
-        i, j = int(result_pairs[idx, 0]), int(result_pairs[idx, 1])
-        if gt_mask[i, j] > 0:
-            n_res += 1
-            gt_idx = gt_mask[i, j]
-            p = transformation_error(np.linalg.inv(gt[gt_idx]) @ result[idx], gt_info[gt_idx])
-            errors[idx] = p
-            good += p <= err2
-            flags.append(0 if p <= err2 else 1)
-        else:
-            flags.append(2)
-    precision = good / (n_res if n_res else 1e6)
-    return precision, good / n_gt, flags, errors
+    """(:223-282) -> precision, recall, flags (0 good / 1 bad / 2 not in gt), per-pair errors.  Whole scene at once: a fragment x
+    fragment lookup table of the tested ground-truth pairs (non-consecutive only; like the reference's, it stores the ground-truth INDEX,
+    so index 0 can never be matched), one batched inverse / quaternion / quadratic form for every estimated pair found in it."""
+    thr = err2 ** 2
+    gi, gj = np.asarray(gt_pairs[:, 0], dtype=np.int64), np.asarray(gt_pairs[:, 1], dtype=np.int64)
+    table = np.zeros((num_fragment, num_fragment), dtype=np.int64)
+    tested = np.nonzero(gj - gi > 1)[0]
+    table[gi[tested], gj[tested]] = tested                      # (a repeated pair keeps its last index, as the reference's loop does)
+    n_gt = int(np.count_nonzero(table))
+    ri, rj = np.asarray(result_pairs[:, 0], dtype=np.int64), np.asarray(result_pairs[:, 1], dtype=np.int64)
+    k = table[ri, rj]
+    hit = k > 0
+    errors = np.full(len(ri), np.nan)
+    if hit.any():
+        errors[hit] = transformation_error(np.linalg.inv(gt[k[hit]]) @ np.asarray(result, np.float64)[hit], gt_info[k[hit]])
+    good = errors <= thr                                        # NaN (not in gt) compares False
+    flags = np.where(hit, np.where(good, 0, 1), 2).tolist()
+    n_good, n_res = int(good.sum()), int(hit.sum())
+    return n_good / (n_res if n_res else 1e6), n_good / n_gt, flags, errors
 
 
 def rotation_error_deg(R_gt, R_est):
@@ -97,13 +103,17 @@ def benchmark(est_folder, gt_folder):
     precision, recall, n_valids, med_re, med_te = [], [], [], [], []
     for idx, scene in enumerate(scenes):
         gt_pairs, gt_traj = read_trajectory(os.path.join(gt_folder, scene, 'gt.log'))
-        n_valid = int(sum(abs(int(e[0]) - int(e[1])) > 1 for e in gt_pairs))
+        gt_ij = gt_pairs[:, :2].astype(np.int64)
+        n_valid = int(np.count_nonzero(np.abs(gt_ij[:, 0] - gt_ij[:, 1]) > 1))
         n_fragments, gt_info = read_trajectory_info(os.path.join(gt_folder, scene, 'gt.info'))
         est_pairs, est_traj = read_trajectory(os.path.join(est_folder, scene, 'est.log'))
         p, r, flags, _ = evaluate_registration(n_fragments, est_traj, est_pairs, gt_pairs, gt_traj, gt_info)
         # ground truth of every estimated pair (extract_corresponding_trajectors :152-171)
-        lut = {(a, b): k for k, (a, b, _) in enumerate(gt_pairs)}
-        ext = np.stack([gt_traj[lut[(a, b)]] if (a, b) in lut else np.zeros((4, 4)) for a, b, _ in est_pairs])
+        where = np.full((n_fragments, n_fragments), -1, dtype=np.int64)
+        where[gt_ij[:, 0], gt_ij[:, 1]] = np.arange(len(gt_ij))
+        est_ij = est_pairs[:, :2].astype(np.int64)
+        found = where[est_ij[:, 0], est_ij[:, 1]]
+        ext = np.where((found >= 0)[:, None, None], gt_traj[np.maximum(found, 0)], 0.0)
         ok = np.asarray(flags) == 0
         re = rotation_error_deg(ext[:, :3, :3], est_traj[:, :3, :3])[ok]
         te = np.linalg.norm(ext[:, :3, 3] - est_traj[:, :3, 3], axis=1)[ok]
