@@ -47,7 +47,7 @@ def mat2quat(M):
     K[:, 0, 0] = R[:, 0, 0] - R[:, 1, 1] - R[:, 2, 2]
     K[:, 1, 0] = R[:, 1, 0] + R[:, 0, 1]; K[:, 1, 1] = R[:, 1, 1] - R[:, 0, 0] - R[:, 2, 2]
     K[:, 2, 0] = R[:, 2, 0] + R[:, 0, 2]; K[:, 2, 1] = R[:, 2, 1] + R[:, 1, 2]; K[:, 2, 2] = R[:, 2, 2] - R[:, 0, 0] - R[:, 1, 1]
-    K[:, 3, 0] = R[:, 1, 2] - R[:, 2, 1]; K[:, 3, 1] = R[:, 2, 0] - R[:, 0, 2]; K[:, 3, 2] = R[:, 0, 1] - R[:, 1, 0]
+    K[:, 3, 0] = R[:, 2, 1] - R[:, 1, 2]; K[:, 3, 1] = R[:, 0, 2] - R[:, 2, 0]; K[:, 3, 2] = R[:, 1, 0] - R[:, 0, 1]
     K[:, 3, 3] = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
     vals, vecs = np.linalg.eigh(K / 3.0)
     q = np.take_along_axis(vecs, np.argmax(vals, axis=1)[:, None, None], axis=2)[:, [3, 0, 1, 2], 0]
