@@ -336,9 +336,11 @@ def compute_overlaps(batch):
 
 
 def compute_overlap(src, tgt, search_voxel_size):
-    """utils/pointcloud.py:8-65 with open3d's KDTreeFlann.search_radius_vector_3d (open3d is not installed here: PARITY
-    UNPINNED for this one function) restated from its documented behaviour: coordinates widened to float64, hits are the
-    points with d2 < radius^2 sorted by distance, `knn_indices[0]` the nearest.  Brute force, small clouds only."""
+    """utils/pointcloud.py:8-65 with open3d's KDTreeFlann.search_radius_vector_3d restated from its documented behaviour (open3d is not
+    installed here): coordinates widened to float64, hits are the points with d2 < radius^2 sorted by distance, `knn_indices[0]` the
+    nearest.  Pinned to the outputs of the REFERENCE's own function run over a scipy-cKDTree stand-in for that one class
+    (oracle/make_golden_overlap.py -> tests/golden/overlap_pairs.npz); open3d's choice among exactly equidistant hits stays unpinned.
+    Brute force, small clouds only."""
     src = np.asarray(src, np.float64); tgt = np.asarray(tgt, np.float64)
     r2 = float(search_voxel_size) ** 2
 

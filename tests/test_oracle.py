@@ -197,3 +197,14 @@ def test_grid_subsample_floor_keys_restatement():
         assert np.abs(got - want).max() < 2e-6                     # float32 in-order sums vs float64 means
         assert np.array_equal(np.floor(got / np.float32(0.05)).astype(np.int64)[cnt == 1], uniq[order][cnt == 1])
         row += len(uniq); off += n
+
+
+def test_compute_overlap_restatement_vs_reference_function_golden():
+    """oracle compute_overlap == the REFERENCE's own function (utils/pointcloud.py:8-65, run from /root/reference by
+    oracle/make_golden_overlap.py over a scipy-cKDTree stand-in for open3d's KDTreeFlann): both has-correspondence masks and the mutual
+    correspondence list, on a jittered copy, a partial overlap, disjoint clouds and real fragments."""
+    g = gold('overlap_pairs')
+    for i in range(int(g['n_cases'])):
+        hs, ht, corr = regtr_ref.compute_overlap(g[f'src_{i}'], g[f'tgt_{i}'], float(g[f'radius_{i}']))
+        assert np.array_equal(hs, g[f'has_src_{i}']) and np.array_equal(ht, g[f'has_tgt_{i}']), i
+        assert np.array_equal(corr, g[f'corr_{i}']), i
