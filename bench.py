@@ -175,6 +175,11 @@ def pmc_traffic(pairs, points, shuffle, detail):
     detail['traffic_source'] = t.get('source')
     detail['traffic_code'] = t.get('code')
     detail['alg_bytes_per_launch'] = detail['alg_gather_bytes_per_step'] / detail['launches_per_step']
+    # the candid companion of `frac`: bytes the counters saw MOVE through HBM per launch / launch time / peak.  The 40x re-read feature rows are
+    # served by L2 / Infinity Cache, so this is far below the algorithmic fraction -- the gather is not an HBM stream (DESIGN sections 3, 8)
+    detail['counter_hbm_GBs'] = t['hbm_bytes_per_launch'] / (detail['avg_launch_us'] * 1e-6) / 1e9
+    detail['counter_hbm_frac_of_peak'] = detail['counter_hbm_GBs'] / HBM_PEAK_GBS
+    detail['traffic_over_algorithmic'] = t['hbm_bytes_per_launch'] / detail['alg_bytes_per_launch']
     return t['hbm_bytes_per_launch']
 
 

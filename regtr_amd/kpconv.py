@@ -57,6 +57,9 @@ def _prepared(cache, key, param, fn):
     return ent[1]
 
 
+CAPACITY_MIN_POINTS = 262144      # below this many input points every level is sized at N_0 (nothing to save, no rebuild risk)
+
+
 class Preprocessor(nn.Module):
     """Computes the metadata used for KPConv (kpconv.py:291 / :417).  One host synchronisation per call: the whole
     pyramid is enqueued against capacity-sized buffers, then the per-level segment offsets are read back once."""
@@ -133,7 +136,8 @@ class Preprocessor(nn.Module):
             K = limits[layer]
             strided = 'pool' in block or 'strided' in block
             ratio = self.level_capacity[layer + 1] if layer + 1 < len(self.level_capacity) else self.level_capacity[-1]
-            cap_next = cap if ref_order else min(cap, max(int(n0 * ratio) + 64, 1))          # (parity mode replays containers over whole clouds)
+            # (parity mode replays containers over whole clouds; a pair or two per forward: the tables are small, full capacity)
+            cap_next = cap if (ref_order or n0 < CAPACITY_MIN_POINTS) else min(cap, max(int(n0 * ratio) + 64, 1))
             dl = 2 * r_normal / cfg.conv_radius                                          # :363
             conv_i = pool_p = pool_seg = pool_i = None
             conv_w = pool_w = K
