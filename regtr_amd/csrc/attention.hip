@@ -39,7 +39,7 @@ __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r 
 // launcher's choice for a pair or two per forward, where a launch is only ~200 single-wave workgroups and its duration is one wave's
 // serial walk over all keys: 32 -> 13 us per launch at one 3DMatch pair, twelve launches per forward.
 template <int KS>
-__global__ void __launch_bounds__(KS * RG_WAVE) k_mha_fwd(MhaArgs g)
+__global__ void __launch_bounds__(KS * RG_WAVE) __attribute__((amdgpu_waves_per_eu(2))) k_mha_fwd(MhaArgs g)
 {
     __shared__ float KVs[KS][2 * TK * LDS_STRIDE];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -264,7 +264,10 @@ __device__ __forceinline__ void f16_mma(const bf16x8 (&a)[2], const bf16x8 (&b)[
 }
 
 template <int NP, bool F16 = false>
-__global__ void __launch_bounds__(BW * RG_WAVE) k_mha_fwd_bf16(MhaArgs g)
+// (waves_per_eu: with a register budget of at most 256 per lane hipcc keeps the MFMA accumulators in VGPRs; without it the budget is 512, the
+//  accumulators go to AGPRs and every softmax step pays v_accvgpr_read / _write copies -- 288 of the 1151 vector instructions of the f16 pair
+//  form, and 160 registers instead of 124: three waves per SIMD instead of four)
+__global__ void __launch_bounds__(BW * RG_WAVE) __attribute__((amdgpu_waves_per_eu(3))) k_mha_fwd_bf16(MhaArgs g)
 {
     __shared__ __align__(16) unsigned char Ks[2][NP][TK * BROW];      // [buffer][plane][key][32 channels]
     __shared__ __align__(16) unsigned char Vt[2][NP][HD * BROW];      // [buffer][plane][channel][32 key slots]
@@ -489,7 +492,7 @@ struct AttnXyzArgs {
 };
 
 template <int HDX>
-__global__ void __launch_bounds__(RG_WAVE) k_attn_xyz(AttnXyzArgs g)
+__global__ void __launch_bounds__(RG_WAVE) __attribute__((amdgpu_waves_per_eu(2))) k_attn_xyz(AttnXyzArgs g)
 {
     constexpr int KS = HDX + 1;                       // odd row stride: conflict-free fragment reads
     extern __shared__ float smem_x[];

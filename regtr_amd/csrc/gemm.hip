@@ -97,7 +97,7 @@ __device__ __forceinline__ unsigned load_tiles(const GemmArgs& g, int m0, int n0
 // WMW x WNW waves, each a 32x32 accumulator
 // ALIGNED_A / ALIGNED_B: the operand may be read as float4 (the thin head Linears -- N = 3, 1 -- still stream their A operand so)
 template <bool ALIGNED_A, bool ALIGNED_B, int WMW, int WNW>
-__global__ void __launch_bounds__(256) k_gemm_f32(GemmArgs g)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_gemm_f32(GemmArgs g)
 {
     constexpr int BM = 32 * WMW, BN = 32 * WNW, LDB_S = BN + 1;
     __shared__ float As[2][BM * LDA_S];
