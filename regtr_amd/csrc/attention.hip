@@ -205,6 +205,19 @@ __device__ __forceinline__ unsigned bf_pack(float a, float b)
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8v __attribute__((ext_vector_type(8)));
 constexpr float MHA_F16_SCALE = 2048.f;
+// development A-B switches (REGTR_VARIANT_FLAGS): measured on one box with tools/mha_bench.py (128 clouds of ~295 tokens), per launch:
+// accumulators in AGPRs (no register budget) 132-135 us, in VGPRs 126-130 us, + the last-tile-only key mask and the
+// v_permlane32_swap exchange 122-125 us.  (Vector conversions -- v_cvt_pk_f16_f32 -- for the pair split: no change, hipcc's SLP pass
+// already packs most of the scalar form.)
+#ifndef MHA_WAVES_ATTR
+#define MHA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+#ifndef MHA_OPT_SWAP
+#define MHA_OPT_SWAP 1
+#endif
+#ifndef MHA_OPT_MASK
+#define MHA_OPT_MASK 1
+#endif
 __device__ __forceinline__ unsigned f16_pack(float a, float b)
 {
     f16x2v v;
@@ -263,11 +276,32 @@ __device__ __forceinline__ void f16_mma(const bf16x8 (&a)[2], const bf16x8 (&b)[
     lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8v, a[0]), __builtin_bit_cast(f16x8v, b[1]), lo, 0, 0, 0);
 }
 
+// combine a value of lane l with that of lane l ^ 32 (the two half-waves hold complementary key sets of the same 32 queries):
+// v_permlane32_swap_b32 exchanges the upper half of one register with the lower half of the other, so after swapping x with a copy of
+// itself the two registers hold (low half's value, high half's value) in EVERY lane -- one VALU instruction where __shfl_xor goes
+// through ds_bpermute_b32 and a wait on LDS.  max and + are commutative: both halves get bit-identical results.
+__device__ __forceinline__ float mha_max_halves(float x)
+{
+#if !MHA_OPT_SWAP
+    return fmaxf(x, __shfl_xor(x, 32, RG_WAVE));
+#endif
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float mha_sum_halves(float x)
+{
+#if !MHA_OPT_SWAP
+    return x + __shfl_xor(x, 32, RG_WAVE);
+#endif
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int NP, bool F16 = false>
 // (waves_per_eu: with a register budget of at most 256 per lane hipcc keeps the MFMA accumulators in VGPRs; without it the budget is 512, the
 //  accumulators go to AGPRs and every softmax step pays v_accvgpr_read / _write copies -- 288 of the 1151 vector instructions of the f16 pair
 //  form, and 160 registers instead of 124: three waves per SIMD instead of four)
-__global__ void __launch_bounds__(BW * RG_WAVE) __attribute__((amdgpu_waves_per_eu(3))) k_mha_fwd_bf16(MhaArgs g)
+__global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(MhaArgs g)
 {
     __shared__ __align__(16) unsigned char Ks[2][NP][TK * BROW];      // [buffer][plane][key][32 channels]
     __shared__ __align__(16) unsigned char Vt[2][NP][HD * BROW];      // [buffer][plane][channel][32 key slots]
@@ -401,13 +435,15 @@ __global__ void __launch_bounds__(BW * RG_WAVE) __attribute__((amdgpu_waves_per_
                 for (int r = 0; r < 16; r++) sc[r] += sc_lo[r] * (1.0f / MHA_F16_SCALE);
             }
             MHA_STAMP(2);
+            if (!MHA_OPT_MASK || kt + TK > nk) {       // (workgroup-uniform: only the last tile of a cloud has keys past the end)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (kt + acc_row(r, hi) >= nk) sc[r] = -INFINITY;
+            }
             float mx = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                if (kt + acc_row(r, hi) >= nk) sc[r] = -INFINITY;
-                mx = fmaxf(mx, sc[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, RG_WAVE));
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, sc[r]);
+            mx = mha_max_halves(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
@@ -417,7 +453,7 @@ __global__ void __launch_bounds__(BW * RG_WAVE) __attribute__((amdgpu_waves_per_
                 pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
                 psum += pr[r];
             }
-            psum += __shfl_xor(psum, 32, RG_WAVE);
+            psum = mha_sum_halves(psum);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
