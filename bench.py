@@ -565,6 +565,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-strict-f32', action='store_true', help="skip the side measurement of compute_dtype 'fp32x3' on the same workload")
+    ap.add_argument('--no-range-check', action='store_true', help='diagnostic: cfg.f16_range_check off -- no status-word wait at the end of a forward, so consecutive forwards are enqueued back to back')
     ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
     ap.add_argument('--collect-pmc', action='store_true', help='run the rocprofv3 counter passes behind roofline.traffic on this workload and write profiles/pmc_traffic.json (stamped with the code version)')
     ap.add_argument('--pmc-tag', default='r04', help=argparse.SUPPRESS)
@@ -622,6 +623,8 @@ def main():
     n_local = int(pair_ids.numel())
     cfg, model, pairs, batch = build_workload(args.config, n_local, args.points, args.shuffle, rank, dev, dtype, args.parity_mode,
                                               distinct=args.distinct_pairs if lomatch else None)
+    if args.no_range_check:
+        model._range_check = False
 
     def step():
         poses, out = [], None
