@@ -257,6 +257,10 @@ __device__ __forceinline__ void rg_buf_store(__amdgpu_buffer_rsrc_t r, unsigned 
 #endif
 }
 
+typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
+#ifndef RG_C1_PIPELINE
+#define RG_C1_PIPELINE 1          // development A-B (REGTR_VARIANT_FLAGS=-DRG_C1_PIPELINE=0): the one-group-per-wave Cin = 1 gather
+#endif
 #ifndef RG_MG_WAVES_PER_EU
 #define RG_MG_WAVES_PER_EU 3
 #endif
@@ -340,6 +344,10 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
         }
         __builtin_amdgcn_wave_barrier();
         // ---- influences of kernel point k for neighbours h = 4 j + hh   (the A operands)
+        // (Measured, round 4: the same arithmetic on the packed-float32 instructions -- neighbour pairs interleaved in LDS, v_pk_add / v_pk_mul /
+        //  v_pk_fma, 75 instead of 120 vector instructions per query -- is bit-identical and NOT faster here: level 0 2118 vs 2114 us, level-0
+        //  pool 545 vs 520, level 1 594 vs 584; six more registers cost the Cin = 32 form a wave per SIMD.  This kernel is not bound by the
+        //  influence arithmetic; the Cin = 1 kernel below, which is nothing else, keeps the packed form.)
         float w[J];
         unsigned row[J];       // byte offset of the neighbour's feature row; RG_OOB for a shadow neighbour (reads as zeros)
 #pragma unroll
@@ -638,22 +646,24 @@ __global__ void __launch_bounds__(FU_WAVES * RG_WAVE) k_kpconv_fused(FusedArgs g
 
 // Cin == 1 (first encoder block, features = ones): no channel dimension to spread over lanes, so lanes are
 // (query, kernel point) pairs: 4 queries x 16 kernel points per wave, each lane walks its query's neighbours once and
-// accumulates influence x feature directly -- no influence tile in LDS, 6 floats of LDS per neighbour instead of 22.
+// accumulates influence x feature directly -- no influence tile in LDS, 5 floats of LDS per neighbour instead of 22.
+// The kernel is pure vector ALU (600 influences per query), so the neighbours are walked TWO at a time on the packed-float32
+// instructions (v_pk_add / v_pk_mul / v_pk_fma: the same IEEE operations, two per instruction): the LDS image holds neighbour PAIRS
+// (rows padded to an even length), one 8-byte read per quantity and pair.
 __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(GatherArgs g)
 {
     constexpr int QW = 4;
     extern __shared__ __align__(16) float smem[];
     const int wave = threadIdx.x >> 6, lane = rg_lane();
-    const int H = g.H;
-    float* rel_s = smem + (size_t)wave * QW * H * 5;      // rel[QW][H][3] | x[QW][H] | flag[QW][H]
-    float* xs_s = rel_s + QW * H * 3;
-    float* flg_s = xs_s + QW * H;
+    const int H = g.H, HP = (H + 1) & ~1, NPAIR = HP >> 1;
+    // per (query, neighbour pair): relx[2] | rely[2] | relz[2] | x[2] | flag[2] -- 40 bytes, so the walk below needs ONE address register
+    float* pair_s = smem + (size_t)wave * QW * NPAIR * 10;
     const int q0 = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * QW;
     if (q0 >= g.nq) return;
-    for (int e = lane; e < QW * H; e += RG_WAVE) {
-        const int qi = e / H, h = e - qi * H, q = q0 + qi;
+    for (int e = lane; e < QW * HP; e += RG_WAVE) {
+        const int qi = e / HP, h = e - qi * HP, q = q0 + qi;
         float rx = 1e6f, ry = 1e6f, rz = 1e6f, f = 0.f, x1 = 0.f;
-        if (q < g.nq) {
+        if (q < g.nq && h < H) {
             const int idx = g.nbr[(size_t)q * H + h];
             float sx = 1e6f, sy = 1e6f, sz = 1e6f;
             if (idx < g.ns) {
@@ -667,7 +677,8 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
             }
             rx = sx - g.q_xyz[3 * (size_t)q]; ry = sy - g.q_xyz[3 * (size_t)q + 1]; rz = sz - g.q_xyz[3 * (size_t)q + 2];
         }
-        rel_s[3 * e] = rx; rel_s[3 * e + 1] = ry; rel_s[3 * e + 2] = rz; xs_s[e] = x1; flg_s[e] = f;
+        float* d = pair_s + (qi * NPAIR + (h >> 1)) * 10 + (h & 1);      // (the pad slot of an odd H: a shadow neighbour, influence 0)
+        d[0] = rx; d[2] = ry; d[4] = rz; d[6] = x1; d[8] = f;
     }
     __builtin_amdgcn_wave_barrier();
     const int qi = lane >> 4, k = lane & 15, q = q0 + qi;
@@ -675,21 +686,131 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1(Gat
     const bool kvalid = k < g.KP;
     const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
     const float inv_extent = 1.0f / g.extent;
+    const rg_f32x2 ninv{-inv_extent, -inv_extent}, one{1.f, 1.f};
     float acc = 0.f, cnt = 0.f;
-    for (int h = 0; h < H; h++) {
-        const int e = qi * H + h;
-        const float dx = rel_s[3 * e] - kx, dy = rel_s[3 * e + 1] - ky, dz = rel_s[3 * e + 2] - kz;
-        float d2;
+    const float* pp = pair_s + qi * NPAIR * 10;
+    for (int p = 0; p < NPAIR; p++, pp += 10) {
+        const rg_f32x2 dx = *(const rg_f32x2*)(pp) - kx, dy = *(const rg_f32x2*)(pp + 2) - ky, dz = *(const rg_f32x2*)(pp + 4) - kz;
+        const rg_f32x2 xv = *(const rg_f32x2*)(pp + 6), fv = *(const rg_f32x2*)(pp + 8);
+        rg_f32x2 d2;
         {
 #pragma clang fp contract(off)
-            d2 = (dx * dx + dy * dy) + dz * dz;
+            d2 = (dx * dx + dy * dy) + dz * dz;                                            // kpconv_blocks.py:326-329
         }
-        const float wv = fmaxf(1.f - __builtin_amdgcn_sqrtf(d2) * inv_extent, 0.f);
-        acc = fmaf(wv, xs_s[e], acc);
-        cnt += flg_s[e];
+        const rg_f32x2 sq{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+        const rg_f32x2 t = __builtin_elementwise_fma(sq, ninv, one);                        // 1 - d / extent (:368)
+        acc = fmaf(fmaxf(t.x, 0.f), xv.x, acc);                                            // (neighbour order kept)
+        acc = fmaf(fmaxf(t.y, 0.f), xv.y, acc);
+        cnt += fv.x + fv.y;                                                                // (0 / 1 flags: exact in any order)
     }
     if (k < g.ld_wf) g.wf[(size_t)q * g.ld_wf + k] = kvalid ? acc : 0.f;      // ld_wf = KP, or 16 with a zero pad column
     if (k == 0) g.num[q] = fmaxf(cnt, 1.f);
+}
+
+// The same, software-pipelined over several 4-query groups per wave (packed support records only): the kernel above spends most of a wave's
+// life in the idx -> record dependency chain of its single group (two memory round trips before the first influence).  Measured at level 0
+// of a 64-pair forward (2.4 M queries, tools/gather_bench.py --levels 7, same box): scalar influences 772 / 760 us, packed pairs 720 / 732,
+// + this pipeline 676 / 681 -- bit-identical outputs; ~570 us is the vector-ALU time of the loop (two quarter-rate v_sqrt_f32 per pair).  Here group g + 1's records and group g + 2's index rows are in flight
+// while group g's influences are computed from LDS (two LDS images, ping-pong).  NS = element slots per lane: 4 HP <= 64 NS.
+template <int NS>
+__global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE) k_kpconv_gather_c1p(GatherArgs g)
+{
+    constexpr int QW = 4;
+    extern __shared__ __align__(16) float smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = rg_lane();
+    const int H = g.H, HP = (H + 1) & ~1, NPAIR = HP >> 1, nq = g.nq, ns = g.ns;
+    float* buf_s = smem + (size_t)wave * 2 * QW * NPAIR * 10;            // [2][QW][NPAIR][10] (layout of k_kpconv_gather_c1)
+    const int groups = g.qpw;                                            // 4-query groups per wave
+    const int qbase = (rg_xcd_block(blockIdx.x, gridDim.x) * GATHER_WAVES + wave) * QW * groups;
+    if (qbase >= nq) return;
+    // element slots of this lane: e = lane + 64 s -> (query e / HP of the group, neighbour column e % HP)
+    int e_q[NS], e_h[NS], e_dst[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const int e = lane + RG_WAVE * s;
+        e_q[s] = e / HP; e_h[s] = e - e_q[s] * HP;
+        if (e >= QW * HP) { e_q[s] = -1; e_h[s] = 0; }
+        e_dst[s] = (e_q[s] * NPAIR + (e_h[s] >> 1)) * 10 + (e_h[s] & 1);
+    }
+    // branch-free loads from clamped addresses (a predicated load drains every outstanding one: tools/isa_scan.py)
+    auto issue_idx = [&](int qg, int (&idx)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int q = qg + (e_q[s] < 0 ? 0 : e_q[s]);
+            const int v = g.nbr[(size_t)(q < nq ? q : nq - 1) * H + (e_h[s] < H ? e_h[s] : H - 1)];
+            idx[s] = (e_q[s] >= 0 && q < nq && e_h[s] < H) ? v : -1;     // -1: not an element (pad slot, query beyond the end)
+        }
+    };
+    struct Rec { float4 r; float qx, qy, qz; };
+    auto issue_rec = [&](int qg, const int (&idx)[NS], Rec (&rec)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int q = qg + (e_q[s] < 0 ? 0 : e_q[s]);
+            const unsigned qc = (unsigned)(q < nq ? q : nq - 1);
+            const int ic = idx[s] < 0 ? 0 : (idx[s] < ns ? idx[s] : ns - 1);
+            rec[s].r = *(const float4*)(g.s_xyzf + 4 * (size_t)ic);
+            rec[s].qx = g.q_xyz[3 * qc]; rec[s].qy = g.q_xyz[3 * qc + 1]; rec[s].qz = g.q_xyz[3 * qc + 2];
+        }
+    };
+    auto stage = [&](float* buf, const int (&idx)[NS], const Rec (&rec)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (e_q[s] < 0) continue;
+            const bool elem = idx[s] >= 0, real = elem && idx[s] < ns;
+            // (as k_kpconv_gather_c1: a shadow neighbour sits at 1e6 - q, a pad slot at 1e6; both have influence 0 and feature 0)
+            const float sx = real ? rec[s].r.x : 1e6f, sy = real ? rec[s].r.y : 1e6f, sz = real ? rec[s].r.z : 1e6f;
+            const float x1 = real ? rec[s].r.w : 0.f;
+            float* d = buf + e_dst[s];
+            d[0] = elem ? sx - rec[s].qx : 1e6f; d[2] = elem ? sy - rec[s].qy : 1e6f; d[4] = elem ? sz - rec[s].qz : 1e6f;
+            d[6] = x1; d[8] = x1 > 0.f ? 1.f : 0.f;
+        }
+    };
+    const int qi = lane >> 4, k = lane & 15;
+    const bool kvalid = k < g.KP;
+    const float kx = kvalid ? g.kp[3 * k] : 0.f, ky = kvalid ? g.kp[3 * k + 1] : 0.f, kz = kvalid ? g.kp[3 * k + 2] : 0.f;
+    const float inv_extent = 1.0f / g.extent;
+    const rg_f32x2 ninv{-inv_extent, -inv_extent}, one{1.f, 1.f};
+
+    int idx_a[NS], idx_b[NS];
+    Rec rec[NS];
+    issue_idx(qbase, idx_a);
+    issue_rec(qbase, idx_a, rec);
+    issue_idx(qbase + QW, idx_b);
+    stage(buf_s, idx_a, rec);
+#pragma unroll 1
+    for (int gi = 0; gi < groups; gi++) {
+        const int qg = qbase + gi * QW;
+        if (qg >= nq) return;                                            // wave-uniform
+        int idx_c[NS];
+        issue_rec(qg + QW, idx_b, rec);                                  // group gi + 1's records (its index row arrived a group ago)
+        issue_idx(qg + 2 * QW, idx_c);
+        __builtin_amdgcn_wave_barrier();
+        const int q = qg + qi;
+        const float* pp = buf_s + (gi & 1) * QW * NPAIR * 10 + qi * NPAIR * 10;
+        float acc = 0.f, cnt = 0.f;
+        for (int p = 0; p < NPAIR; p++, pp += 10) {
+            const rg_f32x2 dx = *(const rg_f32x2*)(pp) - kx, dy = *(const rg_f32x2*)(pp + 2) - ky, dz = *(const rg_f32x2*)(pp + 4) - kz;
+            const rg_f32x2 xv = *(const rg_f32x2*)(pp + 6), fv = *(const rg_f32x2*)(pp + 8);
+            rg_f32x2 d2;
+            {
+#pragma clang fp contract(off)
+                d2 = (dx * dx + dy * dy) + dz * dz;                                        // kpconv_blocks.py:326-329
+            }
+            const rg_f32x2 sq{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+            const rg_f32x2 t = __builtin_elementwise_fma(sq, ninv, one);                    // 1 - d / extent (:368)
+            acc = fmaf(fmaxf(t.x, 0.f), xv.x, acc);
+            acc = fmaf(fmaxf(t.y, 0.f), xv.y, acc);
+            cnt += fv.x + fv.y;
+        }
+        if (q < nq) {
+            if (k < g.ld_wf) g.wf[(size_t)q * g.ld_wf + k] = kvalid ? acc : 0.f;
+            if (k == 0) g.num[q] = fmaxf(cnt, 1.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        stage(buf_s + ((gi + 1) & 1) * QW * NPAIR * 10, idx_b, rec);
+#pragma unroll
+        for (int s = 0; s < NS; s++) idx_b[s] = idx_c[s];
+    }
 }
 
 // out[q, c] = max_h x_pad[nbr[q, h], c]   with a zero shadow row   (kpconv_blocks.py:127-143)
@@ -794,7 +915,23 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     hipStream_t st = (hipStream_t)stream;
     if (Cin == 1) {
         if (x_stats) return RG_ERR_ARG;
-        const size_t lds1 = (size_t)GATHER_WAVES * 4 * H * 5 * sizeof(float);
+        const int HP1 = (H + 1) & ~1;
+        if (RG_C1_PIPELINE && s_xyzf && 4 * HP1 <= 4 * RG_WAVE && nq > 0 && ns > 0) {
+            // groups of 4 queries per wave: up to 8 where the level is large enough to keep ~8 workgroups per CU anyway
+            int groups = (int)(((long long)nq + 256LL * 8 * GATHER_WAVES * 4 - 1) / (256LL * 8 * GATHER_WAVES * 4));
+            groups = groups < 1 ? 1 : (groups > 8 ? 8 : groups);
+          if (groups >= 2) {      // (a pair or two per forward: one group per wave fills the chip better -- 14.3 vs 15.6 us at one pair)
+            g.qpw = groups;
+            const size_t ldsp = (size_t)GATHER_WAVES * 2 * 4 * HP1 * 5 * sizeof(float);
+            const int gridp = rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * 4 * groups));
+            if (4 * HP1 <= 2 * RG_WAVE) k_kpconv_gather_c1p<2><<<gridp, GATHER_WAVES * RG_WAVE, ldsp, st>>>(g);
+            else if (4 * HP1 <= 3 * RG_WAVE) k_kpconv_gather_c1p<3><<<gridp, GATHER_WAVES * RG_WAVE, ldsp, st>>>(g);
+            else k_kpconv_gather_c1p<4><<<gridp, GATHER_WAVES * RG_WAVE, ldsp, st>>>(g);
+            RG_RETURN_IF_LAUNCH_FAILED();
+            return RG_OK;
+          }
+        }
+        const size_t lds1 = (size_t)GATHER_WAVES * 4 * HP1 * 5 * sizeof(float);
         k_kpconv_gather_c1<<<rg_xcd_grid(rg_cdiv(nq, GATHER_WAVES * 4)), GATHER_WAVES * RG_WAVE, lds1, st>>>(g);
         RG_RETURN_IF_LAUNCH_FAILED();
         return RG_OK;

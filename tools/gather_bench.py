@@ -41,8 +41,8 @@ def main():
     torch.manual_seed(0)
     r0 = cfg.first_subsampling_dl * cfg.conv_radius
     total = 0.0
-    for lvl, (Cin, strided) in enumerate([(32, False), (32, True), (64, False), (64, True), (128, False), (128, True), (256, False)]):
-        layer = [0, 0, 1, 1, 2, 2, 3][lvl]
+    for lvl, (Cin, strided) in enumerate([(32, False), (32, True), (64, False), (64, True), (128, False), (128, True), (256, False), (1, False)]):      # (level 7: the first block, Cin = 1)
+        layer = [0, 0, 1, 1, 2, 2, 3, 0][lvl]
         if args.levels and str(lvl) not in args.levels.split(','):
             continue
         s_pts = meta['points'][layer]
@@ -52,14 +52,14 @@ def main():
         ns, nq, H = s_pts.shape[0], q_pts.shape[0], nbr.shape[1]
         radius = r0 * 2 ** layer
         kp = torch.tensor(load_kernels(radius, 15, dimension=3, fixed='center'), dtype=torch.float32, device=dev)
-        x = torch.randn(ns, Cin, device=dev)
+        x = torch.randn(ns, Cin, device=dev) if Cin > 1 else torch.ones(ns, 1, device=dev)
         if args.xpat == 'ones':
             x = torch.ones(ns, Cin, device=dev)
         elif args.xpat == 'chan':
             x = (torch.arange(Cin, device=dev, dtype=torch.float32) + 1).repeat(ns, 1).contiguous()
         elif args.xpat == 'row':
             x = (torch.arange(ns, device=dev, dtype=torch.float32) % 64 + 1)[:, None].repeat(1, Cin).contiguous()
-        st = ops.instnorm_stats(x, seg_s, max(meta['_lens_host'][layer]))
+        st = ops.instnorm_stats(x, seg_s, max(meta['_lens_host'][layer])) if Cin > 1 else None
         wf = torch.empty(nq, 15 * Cin, device=dev); num = torch.empty(nq, device=dev)
         flag = torch.cat((s_pts, (x.sum(1, keepdim=True) > 0).float()), 1).contiguous() if args.pre else None
 
