@@ -69,7 +69,7 @@ template <int KT> __device__ __forceinline__ unsigned sg_swz(unsigned n)
 
 // KT = K / 16 (2, 4, 8); NT = 32-column blocks per workgroup column (1, 2, 4); INFOLD: A' = LeakyReLU(InstanceNorm(A))
 template <int KT, int NT, bool INFOLD>
-__global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_strip(SgArgs g)
+__global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 2) k_gemm_strip(SgArgs g)
 {
     constexpr int K = 16 * KT, CPR = 2 * KT, ROWB = K * 2, NB = 32 * NT;
     extern __shared__ __align__(16) unsigned char Ws[];          // [3][NB][K] bf16, chunk-swizzled | double2 red[SG_WAVES][NB]
@@ -79,6 +79,13 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_str
     const int m0 = blockIdx.x * SG_ROWS, r0 = m0 + 32 * wave;     // the wave's strip
     const int row = r0 + l31;
     const bool row_ok = row < g.M;
+#ifdef SG_PROF
+    long long pt[8]; int pi = 0;
+#define SG_STAMP() do { pt[pi++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SG_STAMP() do {} while (0)
+#endif
+    SG_STAMP();
 
     // ---- the strip's rows first (the long-latency loads), the tile's clouds, then the weights while those fly
     float4 raw[KT][2];
@@ -91,14 +98,33 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_str
         }
     }
     const int4 ti = g.tile_info[blockIdx.x];
-    for (int idx = t; idx < 3 * NB * CPR; idx += SG_WAVES * RG_WAVE) {
-        const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
-        const uint4 v = *(const uint4*)(g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + c * 8);
-        *(uint4*)(Ws + ((size_t)(p * NB + n) * CPR + ((unsigned)c ^ sg_swz<KT>((unsigned)n))) * 16) = v;
+    {
+        // every 16-byte piece of this thread requested before the first is stored: ONE round trip behind the A loads (as a load-store loop
+        // the copy was six dependent round trips, 11-40 k of a wave's ~50 k cycles: profiles/r04_strip_phase_clocks.md)
+        constexpr int WTOT = 3 * NB * CPR, WIT = (WTOT + SG_WAVES * RG_WAVE - 1) / (SG_WAVES * RG_WAVE), WB = KT == 8 ? 3 : (WIT < 6 ? WIT : 6);
+#pragma unroll
+        for (int b0 = 0; b0 < WIT; b0 += WB) {                    // (at most six pieces = 24 registers in flight; three at K = 128, whose fragments fill the file)
+            uint4 wv[WB];
+#pragma unroll
+            for (int it = 0; it < WB; it++) {
+                const int idx = min(t + (b0 + it) * SG_WAVES * RG_WAVE, WTOT - 1);
+                const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
+                wv[it] = *(const uint4*)(g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + c * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < WB; it++) {
+                const int idx = t + (b0 + it) * SG_WAVES * RG_WAVE;
+                if (b0 + it >= WIT || idx >= WTOT) continue;
+                const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
+                *(uint4*)(Ws + ((size_t)(p * NB + n) * CPR + ((unsigned)c ^ sg_swz<KT>((unsigned)n))) * 16) = wv[it];
+            }
+        }
     }
     const int s_lo = ti.x, s_hi = ti.y;
     const bool one_cloud = s_lo == s_hi;                          // workgroup-uniform; almost always
+    SG_STAMP();
     __syncthreads();
+    SG_STAMP();
 
     // ---- A fragments: fold, split
     bf16x8 fa[KT][3];
@@ -128,6 +154,7 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_str
             for (int p = 0; p < 3; p++) fa[ks][p] = __builtin_bit_cast(bf16x8, make_uint4(w[0][p], w[1][p], w[2][p], w[3][p]));
         }
     }
+    SG_STAMP();
     unsigned f_off[KT];
 #pragma unroll
     for (int ks = 0; ks < KT; ks++) f_off[ks] = (unsigned)l31 * ROWB + (((unsigned)(2 * ks + hi)) ^ sg_swz<KT>((unsigned)l31)) * 16u;
@@ -155,16 +182,13 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_str
         }
 
     const int rbase = r0 + 4 * hi;
-    // ---- store
-#pragma unroll
-    for (int j = 0; j < NT; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rw = rbase + (r & 3) + 8 * (r >> 2);
-            if (rw < g.M) g.C[(size_t)rw * g.ldc + n0 + 32 * j + l31] = acc[j][r];
-        }
-    if (!g.stat_partial) return;                                 // workgroup-uniform
-    // ---- statistics of the Linear's own output: per cloud of the tile, per column (kpconv_blocks.py:510-519)
+#ifdef SG_PROF
+    { float z = 0.f; for (int j = 0; j < NT; j++) z += acc[j][0]; if (z == 1.2345e30f) pt[0] = 0; }   // (the accumulators are complete)
+#endif
+    SG_STAMP();
+    // ---- statistics of the Linear's own output: per cloud of the tile, per column (kpconv_blocks.py:510-519) -- BEFORE the stores: the
+    // transposing store below consumes the accumulators in place
+    if (g.stat_partial) {                                        // workgroup-uniform
     double2* red = (double2*)(Ws + (size_t)3 * NB * ROWB);        // [SG_WAVES][NB]
     for (int sg = s_lo; sg <= s_hi; sg++) {                      // workgroup-uniform; one pass almost always
         const int c_lo = sg == s_lo ? ti.z : g.seg_off[sg], c_hi = min(sg == s_lo ? ti.w : g.seg_off[sg + 1], g.M);
@@ -188,6 +212,28 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, KT <= 4 ? 4 : 2) k_gemm_str
         }
         if (sg < s_hi) __syncthreads();                          // red is reused by the next cloud
     }
+    }
+    SG_STAMP();
+    // ---- store: a lane holds a COLUMN strip (rows 4 hi + (r & 3) + 8 (r >> 2) of column l31), every instruction writes two full 128-byte lines.
+    // (Measured, round 4: the 4 x 4 blocks of a lane quad transposed by DPP quad_perm butterflies so that a lane owns four consecutive columns of
+    //  one row -- 4 NT sixteen-byte stores per lane instead of 16 NT dwords, eight full lines per instruction: bit-identical and NOT faster,
+    //  313 vs 287 us on the 0.6 M x 64 -> 256 shape; the wave's time in its store phase is queueing in the memory system, not instruction issue:
+    //  profiles/r04_strip_phase_clocks.md.)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int rw = rbase + (r & 3) + 8 * (r >> 2);
+            if (rw < g.M) g.C[(size_t)rw * g.ldc + n0 + 32 * j + l31] = acc[j][r];
+        }
+#ifdef SG_PROF
+    SG_STAMP();
+    __builtin_amdgcn_s_waitcnt(0);
+    SG_STAMP();
+    if (lane == 0 && (blockIdx.x == 700 || blockIdx.x == 1500) && blockIdx.y == 0 && (wave == 0 || wave == 5))
+        printf("gemm_strip KT %d NT %d wg %d wave %d: loads+Wcopy %lld barrier %lld split %lld mfma %lld stats %lld store-issue %lld drain %lld total %lld\n", KT, NT, (int)blockIdx.x, wave,
+               pt[1] - pt[0], pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5], pt[7] - pt[6], pt[7] - pt[0]);
+#endif
 }
 
 // columns per workgroup column (32, 64 or 128): all of N when N <= 128 and planes + reduction buffer fit 64 KB of LDS, else half

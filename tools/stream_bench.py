@@ -44,3 +44,7 @@ def main():
                                      want_stats=(seg, int(lens.max()))), args.reps)
         ops.use_stream_gemm = True
         print(f'K={K} N={N} M={M} fold={int(fold)}: strip {t_s:.0f} us ({gb / t_s * 1e3:.2f} TB/s) | tiled {t_t:.0f} us ({gb / t_t * 1e3:.2f} TB/s)')
+
+
+if __name__ == "__main__":
+    main()
