@@ -293,11 +293,22 @@ template <int KT, int NB>
 __device__ __forceinline__ void ts_copy_planes(const uint16_t* __restrict__ src /*[3][N][K] of the cloud, at column n0*/, size_t plane,
                                                unsigned char* dst, int t)
 {
-    constexpr int CPR = 2 * KT, K = 16 * KT;
-    for (int idx = t; idx < 3 * NB * CPR; idx += TS_WAVES * RG_WAVE) {
-        const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
-        const uint4 v = *(const uint4*)(src + (size_t)p * plane + (size_t)n * K + c * 8);
-        *(uint4*)(dst + ((size_t)(p * NB + n) * CPR + ((unsigned)c ^ ts_swz<KT>((unsigned)n))) * 16) = v;
+    // LDS-DMA, as k_gemm_strip's weight copy (csrc/gemm_stream.hip): lane i of DMA q is slot 64 q + i = (p NB + n) CPR + cs of the image and
+    // fetches logical chunk cs ^ swz(n) of column n, plane p.  (The load -> ds_write loop this replaces was up to nine dependent round
+    // trips per thread, and the kernel has no registers to batch them in.)
+    constexpr int CPR = 2 * KT, K = 16 * KT, NDMA = 3 * NB * CPR / RG_WAVE;
+    static_assert(3 * NB * CPR % RG_WAVE == 0, "whole DMA instructions");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+#pragma unroll 1                 // (rolled: a DMA returns nothing to wait for, and the addresses of nine of them at once would spill)
+    for (int q0 = 0; q0 < NDMA; q0 += TS_WAVES) {
+        const int q = q0 + wave;
+        if (q < NDMA) {                                              // wave-uniform
+            const int sidx = q * RG_WAVE + lane;
+            const int p = sidx / (NB * CPR), rem = sidx - p * (NB * CPR), n = rem / CPR, cs = rem - n * CPR;
+            __builtin_amdgcn_global_load_lds((const void*)(src + (size_t)p * plane + (size_t)n * K + (((unsigned)cs ^ ts_swz<KT>((unsigned)n)) * 8)),
+                                             (lds_ptr)(dst + (size_t)q * 1024), 16, 0, 0);
+        }
     }
 }
 

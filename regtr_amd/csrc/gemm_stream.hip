@@ -99,31 +99,29 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 
     }
     const int4 ti = g.tile_info[blockIdx.x];
     {
-        // every 16-byte piece of this thread requested before the first is stored: ONE round trip behind the A loads (as a load-store loop
-        // the copy was six dependent round trips, 11-40 k of a wave's ~50 k cycles: profiles/r04_strip_phase_clocks.md)
-        constexpr int WTOT = 3 * NB * CPR, WIT = (WTOT + SG_WAVES * RG_WAVE - 1) / (SG_WAVES * RG_WAVE), WB = KT == 8 ? 3 : (WIT < 6 ? WIT : 6);
+        // the weight planes by LDS-DMA (global_load_lds_dwordx4: 64 sixteen-byte pieces per instruction, no staging registers, every
+        // instruction of the workgroup in flight at once behind the A loads).  A DMA fills LDS lane-linearly, so lane i of DMA q is slot
+        // s = 64 q + i = (p NB + n) CPR + cs of the image and fetches logical chunk cs ^ swz(n) of column n, plane p.
+        // (As a load -> ds_write loop the copy was six dependent round trips per thread -- hipcc keeps the loop rolled, one
+        //  s_waitcnt vmcnt(0) per piece: 11-40 k of a wave's ~50 k cycles, profiles/r04_strip_phase_clocks.md.)
+        constexpr int NDMA = 3 * NB * CPR / RG_WAVE;
+        static_assert(3 * NB * CPR % RG_WAVE == 0, "whole DMA instructions");
+        typedef __attribute__((address_space(3))) void* lds_ptr;
 #pragma unroll
-        for (int b0 = 0; b0 < WIT; b0 += WB) {                    // (at most six pieces = 24 registers in flight; three at K = 128, whose fragments fill the file)
-            uint4 wv[WB];
-#pragma unroll
-            for (int it = 0; it < WB; it++) {
-                const int idx = min(t + (b0 + it) * SG_WAVES * RG_WAVE, WTOT - 1);
-                const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
-                wv[it] = *(const uint4*)(g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + c * 8);
-            }
-#pragma unroll
-            for (int it = 0; it < WB; it++) {
-                const int idx = t + (b0 + it) * SG_WAVES * RG_WAVE;
-                if (b0 + it >= WIT || idx >= WTOT) continue;
-                const int p = idx / (NB * CPR), rem = idx - p * (NB * CPR), n = rem / CPR, c = rem - n * CPR;
-                *(uint4*)(Ws + ((size_t)(p * NB + n) * CPR + ((unsigned)c ^ sg_swz<KT>((unsigned)n))) * 16) = wv[it];
+        for (int q0 = 0; q0 < NDMA; q0 += SG_WAVES) {
+            const int q = q0 + wave;
+            if (q < NDMA) {                                          // wave-uniform
+                const int sidx = q * RG_WAVE + lane;
+                const int p = sidx / (NB * CPR), rem = sidx - p * (NB * CPR), n = rem / CPR, cs = rem - n * CPR;
+                const uint16_t* src = g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + (((unsigned)cs ^ sg_swz<KT>((unsigned)n)) * 8);
+                __builtin_amdgcn_global_load_lds((const void*)src, (lds_ptr)(Ws + (size_t)q * 1024), 16, 0, 0);
             }
         }
     }
     const int s_lo = ti.x, s_hi = ti.y;
     const bool one_cloud = s_lo == s_hi;                          // workgroup-uniform; almost always
     SG_STAMP();
-    __syncthreads();
+    __syncthreads();                                              // (carries the vmcnt(0) that lands the DMA)
     SG_STAMP();
 
     // ---- A fragments: fold, split
