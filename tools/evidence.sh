@@ -2,7 +2,7 @@
 # The evidence run of a round, ONE gpurun call: every GPU test, the default bench line (with CPU baseline), the counter passes behind
 # roofline.traffic (bench.py --collect-pmc), kernel statistics + per-forward trace (rocprofv3), the MFMA / wave-cycle PMC table, every other
 # bench configuration, and the end-to-end harness.  Outputs under gpurun_out/<tag>; the summaries are copied into profiles/<tag>_* afterwards.
-#   gpurun --timeout 1800 -- 'bash tools/evidence.sh r04_y'
+#   gpurun --timeout 1800 -- 'bash tools/evidence.sh r04_x'
 tag=${1:-evidence}; out=gpurun_out/$tag; mkdir -p $out; export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q -rs --durations=5 > $out/pytest.log 2>&1; echo "pytest exit $?" >> $out/pytest.log; tail -6 $out/pytest.log
 timeout 600 python bench.py --collect-pmc --pmc-tag $tag > $out/collect_pmc.log 2>&1; tail -2 $out/collect_pmc.log | cut -c1-400
