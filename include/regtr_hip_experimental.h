@@ -1,8 +1,8 @@
-/* regtr_hip_experimental.h -- entry points of libregtr_hip.so that are NOT part of the drop-in boundary (include/regtr_hip.h) and
+/* regtr_hip_experimental.h -- entry points of libregtr_hip.experimental.so that are NOT part of the drop-in boundary (include/regtr_hip.h) and
  * NOT covered by REGTR_ABI_VERSION: kernels that were built, tested and MEASURED SLOWER than the path the product runs (kept so the
- * measurements in DESIGN.md section 8 can be reproduced), and diagnostics.  Nothing in the default forward calls them; they are
- * reachable through opt-in switches of regtr_amd/ops.py only (REGTR_FUSED_KPCONV, REGTR_BLOCK_TAIL_RES).
- * Signatures here may change or disappear without a version bump. */
+ * measurements in docs/NEGATIVES.md can be reproduced), and diagnostics.  They are compiled ONLY under -DREGTR_EXPERIMENTAL, i.e. into
+ * libregtr_hip.experimental.so (`python -m regtr_amd.build --experimental`, regtr_amd/experimental.py); the shipped libregtr_hip.so
+ * does not contain them and the product has no route to them.  Signatures here may change or disappear without a version bump. */
 #ifndef REGTR_HIP_EXPERIMENTAL_H
 #define REGTR_HIP_EXPERIMENTAL_H
 

@@ -13,7 +13,7 @@ from . import context
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libregtr_hip.so')
-if os.environ.get('REGTR_VARIANT'):      # development only: A/B kernel experiments (regtr_amd/build.py)
+if os.environ.get('REGTR_DEV', '') == '1' and os.environ.get('REGTR_VARIANT'):      # development only: A/B kernel experiments (regtr_amd/build.py)
     LIB_PATH = os.path.join(_HERE, f"libregtr_hip.{os.environ['REGTR_VARIANT']}.so")
 
 _c = ctypes
@@ -81,16 +81,6 @@ SIGNATURES = {
     'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
-# include/regtr_hip_experimental.h: measured-slower experiment kernels and diagnostics, outside the ABI version (opt-in switches only)
-EXPERIMENTAL = {
-    'regtr_gemm_x3_strip_occupancy': (_I, [_I, _I, _I]),
-    'regtr_kpconv_fused_supported': (_I, [_I, _I, _I, _I]),
-    'regtr_kpconv_fused': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _F, _P, _P, _P]),
-    'regtr_block_tail_res_supported': (_I, [_I, _I, _I]),
-    'regtr_block_tail_res_ws_bytes': (_Z, [_I, _I, _I, _I]),
-    'regtr_block_tail_res': (_I, [_P, _I, _P, _F, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _F, _F, _P, _I, _P, _Z, _P]),
-}
-
 _ERR = {-1: 'kernel launch failed', -2: 'invalid argument', -3: 'workspace too small'}
 
 _lib = None
@@ -117,7 +107,7 @@ def _load():
         # upload thread, a second model) each re-acquisition can wait a full switch interval (5 ms): 50-100 ms stalls per forward were
         # measured that way (profiles/r04_e2e_harness.txt)
         _lib = ctypes.PyDLL(LIB_PATH)
-        for name, (res, args) in list(SIGNATURES.items()) + list(EXPERIMENTAL.items()):
+        for name, (res, args) in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args

@@ -1,4 +1,6 @@
-"""Builds regtr_amd/libregtr_hip.so (gfx950) in-tree with hipcc.  `python -m regtr_amd.build [--force]`."""
+"""Builds regtr_amd/libregtr_hip.so (gfx950) in-tree with hipcc.  `python -m regtr_amd.build [--force] [--experimental]`.
+--experimental additionally builds libregtr_hip.experimental.so (-DREGTR_EXPERIMENTAL: the measured-slower experiment kernels of
+include/regtr_hip_experimental.h, which the shipped library does not contain; regtr_amd/experimental.py)."""
 import os
 import subprocess
 import sys
@@ -10,8 +12,6 @@ LIB = os.path.join(HERE, 'libregtr_hip.so')
 # development only: REGTR_VARIANT=name REGTR_VARIANT_FLAGS='-DX=1' builds libregtr_hip.name.so for A/B kernel experiments
 VARIANT = os.environ.get('REGTR_VARIANT', '')
 VARIANT_FLAGS = os.environ.get('REGTR_VARIANT_FLAGS', '').split()
-if VARIANT:
-    LIB = os.path.join(HERE, f'libregtr_hip.{VARIANT}.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
 SOURCES = ['preprocess.hip', 'ref_order.hip', 'kpconv.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_stream.hip', 'block_tail.hip', 'norm.hip', 'attention.hip', 'cross_encoder.hip', 'procrustes.hip']
@@ -59,7 +59,11 @@ def write_build_info():
     return info
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None, variant_flags=None):
+    """variant / variant_flags default to REGTR_VARIANT / REGTR_VARIANT_FLAGS (development builds next to the product library)."""
+    VARIANT = globals()['VARIANT'] if variant is None else variant
+    VARIANT_FLAGS = globals()['VARIANT_FLAGS'] if variant_flags is None else list(variant_flags)
+    LIB = os.path.join(HERE, f'libregtr_hip.{VARIANT}.so') if VARIANT else globals()['LIB']
     objdir = os.path.join(HERE, 'build', VARIANT) if VARIANT else os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
     inc = os.path.join(os.path.dirname(HERE), 'include')
@@ -90,5 +94,12 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_experimental(force=False, verbose=False):
+    """libregtr_hip.experimental.so: the product sources + the experiment kernels (regtr_amd/experimental.py)."""
+    return build(force, verbose, variant='experimental', variant_flags=['-DREGTR_EXPERIMENTAL=1'])
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    if '--experimental' in sys.argv:
+        print(build_experimental(force='--force' in sys.argv, verbose=True))

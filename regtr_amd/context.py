@@ -16,10 +16,10 @@ STATUS_NONFINITE_POSE = 2
 
 class ForwardContext:
     __slots__ = ('device_index', 'f16_pair', 'force_x3', 'status', 'gather_records', 'mha_records', 'gemm_records', 'f16_range_log',
-                 '_dev_ctx', '_prev')
+                 'reference_order', '_dev_ctx', '_prev')
 
     def __init__(self, device=None, f16_pair=False, force_x3=False, status=None, gather_records=None, mha_records=None,
-                 gemm_records=None, f16_range_log=None):
+                 gemm_records=None, f16_range_log=None, reference_order=False):
         if device is None:
             self.device_index = None              # ask torch at launch time
         else:
@@ -34,6 +34,7 @@ class ForwardContext:
         self.mha_records = mha_records
         self.gemm_records = gemm_records
         self.f16_range_log = f16_range_log        # audits: (M, N, K, max |A|, max |W|) of every f16 pair launch (synchronises)
+        self.reference_order = bool(reference_order)    # cpp_wrappers: the reference CPU ops' own row / tie orders (parity mode)
         self._dev_ctx = None
         self._prev = None
 
@@ -81,7 +82,7 @@ def forward(device, **kw):
     """`with context.forward(dev, f16_pair=..., status=...) as ctx:` -- a fresh context on this thread's stack.  Recording lists and the
     audit log of an enclosing context (bench.py / tests wrap model calls in `context.recording(...)`) are inherited."""
     outer = current()
-    for k in ('gather_records', 'mha_records', 'gemm_records', 'f16_range_log'):
+    for k in ('gather_records', 'mha_records', 'gemm_records', 'f16_range_log', 'reference_order'):
         if k not in kw:
             kw[k] = getattr(outer, k)
     return ForwardContext(device, **kw)

@@ -6,25 +6,26 @@
         /root/reference/src/models/backbone_kpconv/cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238 (parse :71-75, return :214-227)
 
 numpy in / numpy out like the originals (torch CUDA tensors are also accepted and returned); shape errors raise
-RuntimeError as the originals do.  Row orders are the canonical ones documented in kpconv.py; after
-`cpp_wrappers.reference_order(True)` they are the reference's own (libstdc++ unordered_map iteration order for the
+RuntimeError as the originals do.  Row orders are the canonical ones documented in kpconv.py; inside
+`with cpp_wrappers.reference_order():` they are the reference's own (libstdc++ unordered_map iteration order for the
 subsampled rows, nanoflann visiting order + std::sort for the neighbour rows -- the parity mode of kpconv.py), and the
-results equal the originals' element for element.
+results equal the originals' element for element.  The switch is a field of the thread-local call context
+(regtr_amd/context.py), not a module global: what one host thread selects, another does not see.
 """
 import numpy as np
 import torch
 
-from . import _lib, ops
-
-
-_REFERENCE_ORDER = [False]
+from . import _lib, context, ops
 
 
 def reference_order(on=True):
-    """Switch both ops to the reference's own row orders (parity mode).  Returns the previous setting."""
-    prev = _REFERENCE_ORDER[0]
-    _REFERENCE_ORDER[0] = bool(on)
-    return prev
+    """`with cpp_wrappers.reference_order():` -- both ops return the reference's own row orders (parity mode) for the calls made
+    inside the block on this thread."""
+    return context.current().derive(reference_order=bool(on))
+
+
+def _ref_order():
+    return context.current().reference_order
 
 
 def _dev():
@@ -69,7 +70,7 @@ class _Subsampling:
         if int(lens.sum()) != pts.shape[0]:
             raise RuntimeError('Wrong number of points : sum(batches) != N')
         with _lib.on_device(pts.device):
-            out, out_seg = ops.grid_subsample(pts, seg, pts.shape[0], float(sampleDl), row_order=int(_REFERENCE_ORDER[0]))
+            out, out_seg = ops.grid_subsample(pts, seg, pts.shape[0], float(sampleDl), row_order=int(_ref_order()))
         oseg = out_seg.cpu().numpy()
         s_len = np.diff(oseg).astype(np.int32)
         if max_p > 0 and (s_len > max_p).any():                                           # grid_subsampling.cpp:181-204
@@ -97,7 +98,7 @@ class _Neighbors:
         if int(qlens.sum()) != q.shape[0] or int(slens.sum()) != s.shape[0]:
             raise RuntimeError('Wrong number of points : sum(batches) != N')
         with _lib.on_device(q.device):
-            if _REFERENCE_ORDER[0]:
+            if _ref_order():
                 tree = ops.KdTree(s, sseg, s.shape[0])
                 _, width = tree.query(q, qseg, q.shape[0], float(radius), 1)          # pass 1: the row width (max in-ball count)
                 idx, _ = tree.query(q, qseg, q.shape[0], float(radius), max(width, 1), list_cap=max(width, 16))

@@ -484,6 +484,7 @@ __global__ void __launch_bounds__(TS_WAVES* RG_WAVE, NT <= 2 ? 4 : 2) k_tail_str
 }
 
 int bt_chunks(int max_len) { return rg_cdiv(max_len > 0 ? max_len : 1, MO_ROWS_WG); }
+#ifdef REGTR_EXPERIMENTAL
 size_t bt_align(size_t b);
 size_t bt_res_ws_bytes(int n_clouds, int max_len, int N, int K1)
 {
@@ -491,6 +492,7 @@ size_t bt_res_ws_bytes(int n_clouds, int max_len, int N, int K1)
     return ((n_clouds * nc * (K1 * K1 + K1) * 8 + 255) & ~(size_t)255) + (((size_t)n_clouds * 3 * N * K1 * 2 + 255) & ~(size_t)255) +
            2 * (((size_t)n_clouds * K1 * 4 + 255) & ~(size_t)255);
 }
+#endif
 size_t bt_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -565,6 +567,7 @@ int regtr_block_tail(const float* A1, int lda1, const float* a1_stats, float a1_
     return RG_OK;
 }
 
+#ifdef REGTR_EXPERIMENTAL      // measured slower (docs/NEGATIVES.md): experiment variant only
 // The tail of a resnet block whose second summand already exists (csrc/block_tail.hip, RES):
 //     Y = LeakyReLU_slope( InstanceNorm(A1' W1) + R )                      r_stats == NULL: identity shortcut (kpconv_blocks.py:736-741)
 //     Y = LeakyReLU_slope( InstanceNorm(A1' W1) + InstanceNorm_r_stats(R) ) r_stats [n_clouds, N, 2]: a Linear shortcut's product
@@ -614,5 +617,7 @@ int regtr_block_tail_res(const float* A1, int lda1, const float* a1_stats, float
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
+
+#endif  // REGTR_EXPERIMENTAL
 
 }  // extern "C"

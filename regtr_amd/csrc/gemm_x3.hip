@@ -1203,6 +1203,7 @@ int regtr_gemm_x3_preferred(int M, int N, int K)
     return K >= 32 ? 1 : 0;
 }
 
+#ifdef REGTR_EXPERIMENTAL
 // Diagnostic: workgroups of the row-strip kernel the runtime will keep resident per CU (hipOccupancyMaxActiveBlocksPerMultiprocessor)
 // for column width cw (2 | 4 blocks of 32), A-ring mode ar (2 | 3; 4 = interleaved, cw 4 only) and the statistics epilogue; -1 = no such variant.
 int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats)
@@ -1216,6 +1217,7 @@ int regtr_gemm_x3_strip_occupancy(int cw, int ar, int stats)
     if (!k || hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, 0) != hipSuccess) return -1;
     return n;
 }
+#endif  // REGTR_EXPERIMENTAL
 
 size_t regtr_gemm_split_weights_bytes(int N, int K)
 {

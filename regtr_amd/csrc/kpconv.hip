@@ -451,8 +451,9 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
 //  for 16-byte stores and cut the contraction to 48 slots.  Correct to 4e-7, a third of the ALU cycles, and still 12-20 % slower than the
 //  kernel above: 40-50 % of a wave's time went into ISSUING the row loads against a full vector-memory pipe -- both kernels ingest the
 //  gathered rows at ~15 B per clock and CU from L2 / Infinity Cache, and that is the limiter at Cin >= 64.  Removed after the
-//  measurement; numbers and phase clocks in profiles/r04_f16_gather_v2.md)
+//  measurement; numbers and phase clocks in profiles/r04_f16_gather_v2.md, docs/NEGATIVES.md.)
 
+#ifdef REGTR_EXPERIMENTAL      // measured slower (docs/NEGATIVES.md): built only into the experiment variant, never into the shipped library
 // ------------------------------------------------------------------------------------------------------------------
 // Gather FUSED with the kernel-point contraction, for the level-0 shape (Cin = Cout = 32, 15 kernel points): the weighted features
 // never go to HBM (4.6 GB written and 4.6 GB read back per level-0 convolution of a 64-pair forward otherwise).
@@ -643,6 +644,8 @@ __global__ void __launch_bounds__(FU_WAVES * RG_WAVE) k_kpconv_fused(FusedArgs g
         par ^= 1;
     }
 }
+
+#endif  // REGTR_EXPERIMENTAL
 
 // Cin == 1 (first encoder block, features = ones): no channel dimension to spread over lanes, so lanes are
 // (query, kernel point) pairs: 4 queries x 16 kernel points per wave, each lane walks its query's neighbours once and
@@ -970,6 +973,7 @@ int regtr_kpconv_gather(const float* q_xyz, int nq, const float* s_xyz, int ns, 
     return RG_OK;
 }
 
+#ifdef REGTR_EXPERIMENTAL
 // 1 when regtr_kpconv_fused serves the convolution: 32 -> 32 channels, 15 kernel points, rows of at most 40 neighbours
 int regtr_kpconv_fused_supported(int Cin, int Cout, int KP, int H) { return (Cin == 32 && Cout == 32 && KP == 15 && H >= 1 && H <= 40) ? 1 : 0; }
 
@@ -993,6 +997,8 @@ int regtr_kpconv_fused(const float* q_xyz, int nq, int ns, const int* nbr, int H
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }
+
+#endif  // REGTR_EXPERIMENTAL
 
 int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream)
 {

@@ -368,11 +368,6 @@ class ResnetBottleneckBlock(nn.Module):
         sc_st = None
         if isinstance(self.unary_shortcut, UnaryBlock):
             shortcut, sc_st = self.unary_shortcut.linear(shortcut, v.seg_post, v.max_post)
-        # unary2's statistics from the second moments of its narrow input; the finished second summand is added in the strip GEMM's
-        # epilogue: the unary2 product is never written and the normalise-add pass disappears (csrc/block_tail.hip, RES)
-        w2 = _prepared(self.unary2._cache, 'w', self.unary2.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
-        if ops.block_tail_res_ok(x, st, w2, shortcut):
-            return ops.block_tail_res(x, st, w2, shortcut, sc_st, v.seg_post, v.max_post)
         # IN + LReLU of the convolution output (:727): folded into unary2's GEMM A-operand load (:730) where the one-shot strip kernel takes
         # the fold (K <= 64); for the deeper levels (K >= 128) the fold would route the product to the tiled kernel (A staged through
         # registers, two barriers per k-tile: 246 us against 118 us for the same shape on the row-strip kernel at level 3), so the narrow

@@ -3,11 +3,10 @@ stream only; every arithmetic step runs in libregtr_hip.so.  Nothing here synchr
 exception: `KdTree` (the reference-order parity mode) reads its row width back.  Every pointer handed to the library is checked
 for device, dtype and contiguity (_lib.ptr / iptr / bptr / dptr)."""
 import math
-import os
 
 import torch
 
-from . import _lib, context
+from . import _lib, context, devflags
 from ._lib import bptr, check, dptr, iptr, ptr, raw, stream
 
 
@@ -156,13 +155,10 @@ class SplitWeight:
 
 # float32-grade contractions as three f16 MFMA terms (the f16 pair split, csrc/gemm_x3.hip) where the row-strip kernel serves the shape,
 # instead of six (planes = 3) / three (planes = 2) bf16 terms.  f16_pair_default: what cfg.compute_dtype 'fp32' asks for (A-B runs:
-# REGTR_F16_PAIR=0).  Whether a given launch takes the format is a field of the per-forward context (context.current().f16_pair, set by
+# REGTR_DEV=1 REGTR_F16_PAIR=0).  Whether a given launch takes the format is a field of the per-forward context (context.current().f16_pair, set by
 # RegTR.forward; `with ops.f16_pair(flag):` for tests and direct op calls) -- not a module global: two models on two host threads do not
 # share it.
-f16_pair_default = os.environ.get('REGTR_F16_PAIR', '1') != '0'
-# N = 32 contractions (level 0) on the f16 pair strip kernel: measured 1044 us against 1084 us + 70 us of separate statistics passes on the
-# exact-f32 kernel, 27.71 vs 27.73 ms per forward (gpurun_out/r03_f7) -- both stream the 4.6 GB operand at ~4.4 TB/s; off
-thin_f16_gemm = os.environ.get('REGTR_F16_THIN', '0') != '0'
+f16_pair_default = devflags.on('REGTR_F16_PAIR')
 _f16_shape = {}
 
 
@@ -243,16 +239,15 @@ def gemm(a, b, bias=None, row_div=None, residual=None, relu=False, out=None, a_s
     ldc = out.stride(0) if M > 1 else N
     n_seg = a_seg_off.numel() - 1 if a_stats is not None else 0
     x3_ok, x3_pref, nb, x3_R, x3_rows = _x3_plan(M, N, K) if sw is not None and sw.planes is not None else (False, False, 0, 0, 0)
-    # (N = 32, the level-0 KPConv contractions: a pure A stream on which the six-term bf16 strip loses to the exact-f32 kernel, 1.20 vs 1.14 ms;
-    #  the f16 pair's three terms are lighter than both -- thin_f16)
+    # (N = 32, the level-0 KPConv contractions, stay on the exact-f32 kernel: a pure A stream on which the six-term bf16 strip loses, 1.20 vs
+    #  1.14 ms, and the f16 pair strip ties -- 27.71 vs 27.73 ms per forward, docs/NEGATIVES.md)
     ctx = context.current()
     use_f16_pair = ctx.f16_pair and not ctx.force_x3
     if ctx.force_x3:
         planes = 3
     f16_range_log = ctx.f16_range_log
-    thin_f16 = use_f16_pair and thin_f16_gemm and N == 32 and a_stats is None and x3_ok and M >= STREAM_MIN_ROWS and f16_pair_ok(M, N, K, want_stats is not None)
     if (x3_ok and lda % 4 == 0 and a.data_ptr() % 16 == 0 and not force_f32_gemm and (N >= 64 or a_stats is None)
-            and (force_x3_gemm or x3_pref or thin_f16)):
+            and (force_x3_gemm or x3_pref)):
         ws = _ws(nb, a.device) if nb else None
         R = x3_R if want_stats is not None else 0
         partial, s_off, n_clouds = None, None, 0
@@ -376,31 +371,6 @@ def _block_tail(x1, x1_stats, row_div, f, w1_kn, w2_kn, seg_off, max_len, slope,
     return (y, st) if want_stats else y
 
 
-def block_tail_res_ok(x1, x1_stats, sw1, res):
-    """regtr_block_tail_res serves this block tail (unary2 from input moments, the finished second summand added in the epilogue)."""
-    M, K1 = x1.shape
-    return bool(use_block_tail and use_block_tail_res and not force_f32_gemm and not force_x3_gemm and M >= STREAM_MIN_ROWS and x1_stats is not None
-                and res.shape == (M, sw1.N) and x1.stride(1) == 1 and res.stride(1) == 1 and x1.stride(0) % 4 == 0
-                and x1.data_ptr() % 16 == 0 and x1_stats.data_ptr() % 16 == 0 and _lib.lib().regtr_block_tail_res_supported(M, sw1.N, K1))
-
-
-def block_tail_res(x1, x1_stats, sw1, res, res_stats, seg_off, max_len, slope=0.1, eps=1e-5):
-    """LeakyReLU(InstanceNorm(x1' @ W1) + r), x1' = LeakyReLU(InstanceNorm(x1)) by x1_stats, r = res (identity / max-pooled shortcut,
-    kpconv_blocks.py:734-741) or InstanceNorm(res) by res_stats (n_clouds, N, 2) (a Linear shortcut's product): unary2 is never written."""
-    L = _lib.lib()
-    M, K1 = x1.shape
-    N = sw1.N
-    n_clouds = seg_off.numel() - 1
-    nb = L.regtr_block_tail_res_ws_bytes(n_clouds, int(max_len), N, K1)
-    ws = torch.empty(nb, dtype=torch.uint8, device=x1.device)
-    ti = tile_segments(seg_off, M, 256)
-    y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
-    check(L.regtr_block_tail_res(raw(x1), x1.stride(0), ptr(x1_stats), slope, ptr(sw1.kn), raw(res), res.stride(0), ptr(res_stats),
-                                 iptr(seg_off), n_clouds, int(max_len), iptr(ti), M, N, K1, eps, slope, ptr(y), N, bptr(ws), nb, stream()),
-          'regtr_block_tail_res')
-    return y
-
-
 def first_block_ok(nq, Cin, KP, Cout):
     """kpconv_norm_lrelu serves the encoder's first block (one input feature, 15 kernel points, 64 outputs, a tall batch)."""
     return bool(use_block_tail and not force_f32_gemm and not force_x3_gemm and Cin == 1 and KP == 15 and nq >= STREAM_MIN_ROWS
@@ -424,24 +394,18 @@ def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_o
 
 
 STREAM_MIN_ROWS = 131072     # below this a forward is launch-bound (a pair or two): the tiled kernels and separate passes are as fast
-use_stream_gemm = os.environ.get('REGTR_STREAM_GEMM', '1') != '0'       # A-B runs
-# level-0 gather + contraction in one launch (regtr_kpconv_fused): correct and tested, but 3.35 ms against 3.08 ms for the two
-# kernels at level 0 of a 64-pair forward (two workgroup barriers per query round) -- off until it is pipelined
-use_fused_kpconv = os.environ.get('REGTR_FUSED_KPCONV', '0') != '0'
-use_block_tail = os.environ.get('REGTR_BLOCK_TAIL', '1') != '0'       # A-B runs: resnet-block tail from input moments
-# ... with the finished second summand added in the epilogue (level 1: unary2 64 -> 256 never written).  Correct and tested, but NOT faster:
-# moments 130 + prepare 68 + strip 410 us against strip GEMM 230 + normalise-add pass 340 us per level-1 block; 30.42 vs 30.17 ms per
-# 64-pair forward -- off by default
-use_block_tail_res = os.environ.get('REGTR_BLOCK_TAIL_RES', '0') != '0'
+# A-B switches of the dispatch: their defaults unless REGTR_DEV=1 is set (regtr_amd/devflags.py) -- a stray variable cannot re-route production
+use_stream_gemm = devflags.on('REGTR_STREAM_GEMM')      # one-shot strip kernel for the shallow levels' Linears
+use_block_tail = devflags.on('REGTR_BLOCK_TAIL')        # resnet-block tail / first block from input moments (csrc/block_tail.hip)
 PRENORM_MIN_ROWS = 65536        # below this a forward is launch-bound: the extra normalise pass costs more than the gather saves
-prenorm_gather = os.environ.get('REGTR_PRENORM', '1') != '0'           # A-B runs: unary1's IN + LReLU applied before the gather
-use_tile_info = os.environ.get('REGTR_TILE_INFO', '1') != '0'       # A-B runs
+prenorm_gather = devflags.on('REGTR_PRENORM')           # unary1's IN + LReLU applied before the gather (packed support records)
+use_tile_info = devflags.on('REGTR_TILE_INFO')
 # unary2's folded InstanceNorm + LeakyReLU operand applied by a separate in-place pass instead (kpconv.py ResnetBottleneckBlock): 1 = where the
-# fold would route to the tiled kernel (K > 64), 2 = everywhere, 0 = never (A-B runs)
-preapply_unary2 = int(os.environ.get('REGTR_PREAPPLY_UNARY2', '1'))
+# fold would route to the tiled kernel (K > 64), 2 = everywhere, 0 = never
+preapply_unary2 = int(devflags.flag('REGTR_PREAPPLY_UNARY2', '1'))
 PREAPPLY_MIN_ROWS = 8192        # (a pair or two per forward is launch-bound: the fold saves the extra launch there)
-# the six cross-encoder layers enqueued by one C call (regtr_cross_encoder_fwd) instead of 72 op calls; A-B runs / tests: '0'
-use_one_call_cross_encoder = os.environ.get('REGTR_ONE_CALL_XENC', '1') != '0'
+# the six cross-encoder layers enqueued by one C call (regtr_cross_encoder_fwd) instead of 72 op calls
+use_one_call_cross_encoder = devflags.on('REGTR_ONE_CALL_XENC')
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel
 force_x3_gemm = False       # tests: route every supported shape to the split kernel, also where it is not the faster one
 
@@ -511,23 +475,6 @@ def kpconv(q_xyz, s_xyz, nbr, x, w_flat, kernel_points, extent, x_stats=None, s_
         flag = torch.empty(ns, dtype=torch.float32, device=dev)
         check(L.regtr_rowsum_positive(ptr(x), ns, Cin, ptr(x_stats), iptr(s_seg_off) if x_stats is not None else None, n_seg,
                                       slope, ptr(flag), stream()), 'regtr_rowsum_positive')
-    # level-0 shape with packed records: gather + contraction + / count in one launch, the weighted features never leave the chip
-    if (use_fused_kpconv and xyzf is not None and Cin > 1 and isinstance(w_flat, SplitWeight) and w_flat.planes is not None
-            and nq >= STREAM_MIN_ROWS and L.regtr_kpconv_fused_supported(Cin, w_flat.N, KP, H)
-            and x.data_ptr() % 16 == 0 and ns * Cin < (1 << 29)):
-        out = torch.empty((nq, w_flat.N), dtype=torch.float32, device=dev)
-        rec = context.current().gather_records
-        if rec is not None:
-            e0, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(2))
-            e0.record()
-        check(L.regtr_kpconv_fused(ptr(q_xyz), nq, ns, iptr(nbr), H, ptr(x), ptr(xyzf), ptr(kernel_points), KP, float(extent),
-                                   bptr(w_flat.planes), ptr(out), stream()), 'regtr_kpconv_fused')
-        if rec is not None:
-            e1.record()
-            rec.append((e0, e1, e1, nq, H, Cin, w_flat.N))
-        if want_stats is None:
-            return out
-        return out, instnorm_stats(out, want_stats[0], want_stats[1])
     wf = torch.empty((nq, KP * Cin), dtype=torch.float32, device=dev)
     num = torch.empty(nq, dtype=torch.float32, device=dev)
     rec = context.current().gather_records

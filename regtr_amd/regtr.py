@@ -11,12 +11,11 @@ sizes after preprocessing): preprocess -> KPConv encoder -> feat_proj -> 6 cross
 correspondence head -> fused weighted-Procrustes.
 """
 import logging
-import os
 
 import torch
 import torch.nn as nn
 
-from . import _lib, context, ops
+from . import _lib, context, devflags, ops
 from .config import as_config
 from .kpconv import KPFEncoder, PreprocessorGPU, _prepared
 from .transformer import TransformerCrossEncoder, TransformerCrossEncoderLayer
@@ -39,7 +38,7 @@ class PositionEmbeddingCoordsSine(nn.Module):
 
 
 # A-B switch and size gate of the two-stream forward (RegTR._forward)
-overlap_preprocessing = os.environ.get('REGTR_OVERLAP', '1') != '0'
+overlap_preprocessing = devflags.on('REGTR_OVERLAP')          # (read only under REGTR_DEV=1)
 OVERLAP_MIN_POINTS = 131072
 
 

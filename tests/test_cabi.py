@@ -23,17 +23,41 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/regtr_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == names, 'ctypes signatures and header disagree'
-    # the opt-in experiment entry points live in their own header, outside the ABI version; nothing is exported that neither declares
-    exp = _header_symbols('regtr_hip_experimental.h')
-    assert sorted(_lib.EXPERIMENTAL) == exp and not set(exp) & set(names)
-    for n in exp:
-        assert hasattr(lib, n), n
+    # the shipped library exports EXACTLY the drop-in boundary: the measured-slower experiment kernels (include/regtr_hip_experimental.h)
+    # are compiled only into libregtr_hip.experimental.so (regtr_amd/experimental.py), outside the ABI version
     import subprocess
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(re.findall(r'\bT (regtr_\w+)', out)))
-    assert exported == sorted(names + exp), set(exported) ^ set(names + exp)
+    assert exported == names, set(exported) ^ set(names)
+    from regtr_amd import experimental
+    exp = _header_symbols('regtr_hip_experimental.h')
+    assert sorted(experimental.SIGNATURES) == exp and not set(exp) & set(names)
+    if experimental.available():
+        out = subprocess.run(['nm', '-D', '--defined-only', experimental.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        assert sorted(set(re.findall(r'\bT (regtr_\w+)', out))) == sorted(names + exp)
     txt = open(os.path.join(ROOT, 'include', 'regtr_hip.h')).read()
     assert int(re.search(r'#define REGTR_ABI_VERSION (\d+)', txt).group(1)) == _lib.ABI_VERSION == lib.regtr_abi_version()
+
+
+def test_stray_env_switch_does_not_reroute():
+    """The A/B switches of the dispatch are read from the environment only under REGTR_DEV=1 (regtr_amd/devflags.py): a stray REGTR_*
+    variable in a production environment changes nothing; and the experiment kernels have no route in the product at all."""
+    import subprocess
+    import sys
+    code = ('import regtr_amd.ops as o, regtr_amd.regtr as r, regtr_amd._lib as l;'
+            'print(o.f16_pair_default, o.use_stream_gemm, o.use_block_tail, o.prenorm_gather, o.use_tile_info, o.preapply_unary2,'
+            ' o.use_one_call_cross_encoder, r.overlap_preprocessing, l.LIB_PATH.endswith("libregtr_hip.so"),'
+            ' hasattr(o, "use_fused_kpconv"), hasattr(o, "block_tail_res"), hasattr(o, "thin_f16_gemm"))')
+    stray = {'REGTR_FUSED_KPCONV': '1', 'REGTR_BLOCK_TAIL_RES': '1', 'REGTR_F16_THIN': '1', 'REGTR_F16_PAIR': '0', 'REGTR_STREAM_GEMM': '0',
+             'REGTR_BLOCK_TAIL': '0', 'REGTR_PRENORM': '0', 'REGTR_TILE_INFO': '0', 'REGTR_PREAPPLY_UNARY2': '0', 'REGTR_ONE_CALL_XENC': '0',
+             'REGTR_OVERLAP': '0', 'REGTR_VARIANT': 'nosuch'}
+    env = {k: v for k, v in os.environ.items() if not k.startswith('REGTR_')}
+    run = lambda e: subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=e, capture_output=True, text=True, check=True).stdout.split()
+    clean = run(env)
+    assert clean == ['True', 'True', 'True', 'True', 'True', '1', 'True', 'True', 'True', 'False', 'False', 'False']
+    assert run(dict(env, **stray)) == clean                                   # stray variables: no routing change
+    dev = run(dict(env, REGTR_DEV='1', **{k: v for k, v in stray.items() if k != 'REGTR_VARIANT'}))
+    assert dev[:8] == ['False', 'False', 'False', 'False', 'False', '0', 'False', 'False'] and dev[9:] == ['False'] * 3
 
 
 def test_context_is_thread_local():

@@ -295,16 +295,13 @@ def test_cpp_wrappers_reference_order(case):
     from regtr_amd import cpp_wrappers
     g = gold(f'native_{case}')
     pts, lens = g['pts'], g['lens']
-    prev = cpp_wrappers.reference_order(True)
-    try:
+    with cpp_wrappers.reference_order():
         s_pts, s_len = cpp_wrappers.grid_subsampling.subsample_batch(pts, lens, sampleDl=float(g['dl']), max_p=0, verbose=0)
         assert np.array_equal(s_len, g['sub_lens']) and np.array_equal(s_pts.view(np.uint32), g['sub_pts'].view(np.uint32))
         nb = cpp_wrappers.radius_neighbors.batch_query(pts, pts, lens, lens, radius=float(g['radius']))
         assert np.array_equal(nb, g['neighbors'])
         pool = cpp_wrappers.radius_neighbors.batch_query(s_pts, pts, s_len, lens, radius=float(g['radius']))
         assert np.array_equal(pool, g['pools'])
-    finally:
-        cpp_wrappers.reference_order(prev)
 
 
 def test_radius_first_k_by_index_vs_restatement():
@@ -444,9 +441,13 @@ def test_fused_instnorm_paths_vs_oracle():
 @pytest.mark.parametrize('nq_take', [1, 3])
 def test_kpconv_fused_vs_two_kernel_path(nq_take):
     """regtr_kpconv_fused (level-0 shape: 32 -> 32 channels, weighted features kept in LDS) against gather + contraction, same inputs:
-    float32 rounding only.  Query counts that are not multiples of the workgroup's 256 (surplus waves run zero tiles)."""
+    float32 rounding only.  Query counts that are not multiples of the workgroup's 256 (surplus waves run zero tiles).
+    The kernel is NOT in the product library (measured slower, docs/NEGATIVES.md): libregtr_hip.experimental.so, regtr_amd/experimental.py."""
     from oracle import native
+    from regtr_amd import experimental
     from regtr_amd.kernel_points import K015_CENTER
+    if not experimental.available():
+        pytest.skip('libregtr_hip.experimental.so not built (python -m regtr_amd.build --experimental)')
     ops = _ops()
     rng = np.random.default_rng(21)
     clouds = [synth_cloud(rng, 3000), synth_cloud(rng, 2101) + 6.0]
@@ -466,15 +467,8 @@ def test_kpconv_fused_vs_two_kernel_path(nq_take):
     sw = ops.SplitWeight(to_dev(w), 'kn')
     assert sw.planes is not None
     args = (to_dev(q), to_dev(s), to_dev(idx), xd, sw, to_dev(kp), r * 0.8)
-    prev = (ops.STREAM_MIN_ROWS, ops.use_fused_kpconv)
-    try:
-        ops.STREAM_MIN_ROWS = 1
-        ops.use_fused_kpconv = True
-        fused = ops.kpconv(*args, xyzf=xyzf)
-        ops.use_fused_kpconv = False
-        plain = ops.kpconv(*args, xyzf=xyzf)
-    finally:
-        ops.STREAM_MIN_ROWS, ops.use_fused_kpconv = prev
+    fused = experimental.kpconv_fused(args[0], args[2], xd, xyzf, sw, args[5], r * 0.8)       # the experiment library
+    plain = ops.kpconv(*args, xyzf=xyzf)                                                         # the product path
     assert (fused - plain).abs().max().item() < 3e-6 * max(1.0, plain.abs().max().item())
 
 
@@ -585,7 +579,11 @@ def test_gemm_stream_vs_exact_f32(lens, K, N):
 def test_block_tail_res_vs_separate_ops(lens, linear_shortcut):
     """regtr_block_tail_res (level-1 resnet tails: unary2's statistics from the 64 x 64 second moments of its input, the product never
     written, the finished second summand -- identity / max-pooled shortcut, or a Linear shortcut's product with its statistics --
-    added in the epilogue) against unary2 GEMM + instnorm_apply with the residual."""
+    added in the epilogue) against unary2 GEMM + instnorm_apply with the residual.  Experiment library only (measured slower,
+    docs/NEGATIVES.md): the product neither contains nor routes to it."""
+    from regtr_amd import experimental
+    if not experimental.available():
+        pytest.skip('libregtr_hip.experimental.so not built (python -m regtr_amd.build --experimental)')
     ops = _ops()
     rng = np.random.default_rng(len(lens) + 7)
     M, K1, N = sum(lens), 64, 256
@@ -599,13 +597,7 @@ def test_block_tail_res_vs_separate_ops(lens, linear_shortcut):
     sw1 = ops.SplitWeight(to_dev(w1), 'nk')
     x1_st = ops.instnorm_stats(x1d, seg, max(lens))
     r_st = ops.instnorm_stats(rd, seg, max(lens)) if linear_shortcut else None
-    prev = ops.use_block_tail_res
-    ops.use_block_tail_res = True
-    try:
-        assert ops.block_tail_res_ok(x1d, x1_st, sw1, rd) == (M >= ops.STREAM_MIN_ROWS)      # (off by default: a speed choice)
-    finally:
-        ops.use_block_tail_res = prev
-    y = ops.block_tail_res(x1d, x1_st, sw1, rd, r_st, seg, max(lens))
+    y = experimental.block_tail_res(x1d, x1_st, sw1, rd, r_st, seg, max(lens))
     u, u_st = ops.gemm(x1d, sw1, a_stats=x1_st, a_seg_off=seg, want_stats=(seg, max(lens)))
     ref = ops.instnorm_apply(u, seg, max(lens), u_st, residual=rd, res_stats=r_st, lrelu=True)
     assert (y - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())

@@ -194,8 +194,7 @@ def test_stress_100k_parity_mode_tables_equal_reference():
         pytest.skip('oracle/_ref not present')
     src, tgt = _pair()
     pts = np.concatenate([src, tgt]); lens = np.array([len(src), len(tgt)], np.int32)
-    prev = cpp_wrappers.reference_order(True)
-    try:
+    with cpp_wrappers.reference_order():
         sub, sl = cpp_wrappers.grid_subsampling.subsample_batch(pts, lens, sampleDl=0.05)
         rsub, rsl = native.ref_subsample_batch(pts, lens, 0.05)
         assert np.array_equal(sl, rsl) and np.array_equal(sub.view(np.uint32), rsub.view(np.uint32))
@@ -203,5 +202,3 @@ def test_stress_100k_parity_mode_tables_equal_reference():
                               native.ref_batch_query(pts, pts, lens, lens, 0.0625))
         assert np.array_equal(cpp_wrappers.radius_neighbors.batch_query(sub, pts, sl, lens, radius=0.0625),
                               native.ref_batch_query(sub, pts, sl, lens, 0.0625))
-    finally:
-        cpp_wrappers.reference_order(prev)
