@@ -59,15 +59,38 @@ def measure_kpconv_roofline(model, batch, reps=5):
     # WF intermediate it writes is an implementation artefact, not algorithmic traffic)
     alg_gather = sum(r[3] * r[4] * (4 + 12 + 4 * r[5]) + r[3] * 12 for r in records)
     n_launch = len(records)
+    shapes = {}
+    for r in records:
+        d = shapes.setdefault((r[3], r[4], r[5]), [0.0, 0])
+        d[0] += r[0].elapsed_time(r[1]) * 1e-3; d[1] += 1
+    by_shape = [{'queries': nq, 'H': H, 'Cin': cin, 'launches_per_step': n // reps, 'us': round(t / n * 1e6, 1),
+                 'alg_GBs': round((nq * H * (4 + 12 + 4 * cin) + nq * 12) / (t / n) / 1e9), 'kernel': 'k_kpconv_gather_c1p' if cin == 1 else 'k_kpconv_gather_mfma'}
+                for (nq, H, cin), (t, n) in sorted(shapes.items(), key=lambda kv: -kv[1][0])]
     return {
-        'kernel': 'k_kpconv_gather',
-        'launches_per_step': n_launch // reps,
+        'kernel': 'k_kpconv_gather_* (every KPConv gather launch of a forward, the first block\'s Cin = 1 gather included)',
+        'launches_per_step': n_launch // reps, 'by_shape': by_shape,
         'avg_launch_us': t_gather / n_launch * 1e6,
         'achieved_gather_kernel_GBs': alg_gather / t_gather / 1e9,
         'achieved_kpconv_op_GBs': alg / (t_gather + t_gemm) / 1e9,
         'alg_bytes_per_step': alg / reps, 'alg_gather_bytes_per_step': alg_gather / reps,
         'gather_s_per_step': t_gather / reps, 'gemm_s_per_step': t_gemm / reps,
     }
+
+
+def measure_preprocess(model, batch, reps=5):
+    """The preprocessing pyramid ALONE (grid subsampling + radius neighbours of every level: kpconv.py:426-537), event-timed on one stream
+    -- in a forward most of it runs under the level-0 convolutions on the second stream, so this is its cost, not its exposed time."""
+    clouds = list(batch['src_xyz']) + list(batch['tgt_xyz'])
+    model.preprocessor(clouds)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        meta = model.preprocessor(clouds)
+    e1.record()
+    torch.cuda.synchronize()
+    return {'pyramid_ms_alone': round(e0.elapsed_time(e1) / reps, 3), 'level_points': [int(p.shape[0]) for p in meta['points']],
+            'what': 'grid subsampling + conv / pool radius-neighbour tables of every level, one stream, nothing overlapped'}
 
 
 def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
@@ -153,7 +176,7 @@ def code_version():
     return v
 
 
-def pmc_traffic(pairs, points, shuffle, detail):
+def pmc_traffic(pairs, points, shuffle, detail, real=False):
     """HBM bytes per KPConv-gather launch from profiles/pmc_traffic.json -- written by `python bench.py --collect-pmc` (counters cannot
     be read from inside the timed process: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this very script).  Reported only
     when that file was taken on THIS workload and THIS code version (kernel source hash); otherwise null, with the reason."""
@@ -163,7 +186,7 @@ def pmc_traffic(pairs, points, shuffle, detail):
     except (OSError, ValueError):
         detail['traffic_note'] = 'profiles/pmc_traffic.json absent: run `python bench.py --collect-pmc` on the GPU'
         return None
-    if t.get('workload') != {'pairs': pairs, 'points': points, 'shuffle': bool(shuffle)}:
+    if real or t.get('workload') != {'pairs': pairs, 'points': points, 'shuffle': bool(shuffle)}:
         detail['traffic_note'] = f"profiles/pmc_traffic.json was taken on another workload ({t.get('workload')})"
         return None
     here = code_version()
@@ -342,11 +365,67 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0, cfg_name='3dmatch'):
                       f'median s/pair {med:.3f}{split}'}
 
 
-def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mode=False, first_id=None, distinct=None):
+REAL_PAIRS = ('3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at')     # tests/golden/*.npz: the clouds of /root/reference/src/demo.py:26-49 examples 0-2
+
+
+def real_pairs(n_pairs, first_id=0):
+    """`--real`: the three REAL 3DMatch pairs the reference ships (demo.py:26-49: red-kitchen 0 / 5, hotel_umd 8 / 15, home_at 38 / 41 -- 6 mm
+    lattice ties, home_at with 22.7 % of its level-0 balls over K = 40; the clouds travel as the committed fixtures tests/golden/3dmatch_*.npz)
+    replicated to `n_pairs`: slots 0-2 are the originals, every further slot is pair (slot % 3) with each cloud under its own random rigid motion
+    (rotation <= 45 deg about a random axis, |t| <= 0.5 m: conf/3dmatch.yaml's augmentation ranges), seeded by the slot id, applied in float32
+    -- 64 different inputs with real-scan neighbourhood statistics.  -> [(src, tgt) float32 numpy]"""
+    from regtr_amd.synthetic import random_se3
+    base = [np.load(os.path.join(ROOT, 'tests', 'golden', f'{n}.npz')) for n in REAL_PAIRS]
+    base = [(np.ascontiguousarray(g['src'], np.float32), np.ascontiguousarray(g['tgt'], np.float32)) for g in base]
+    out = []
+    for i in range(n_pairs):
+        sl = first_id + i
+        s, t = base[sl % len(base)]
+        if sl >= len(base):
+            rng = np.random.default_rng(7000003 + sl)
+            (Rs, ts), (Rt, tt) = random_se3(rng, 45.0, 0.5), random_se3(rng, 45.0, 0.5)
+            s = (s @ Rs.astype(np.float32).T + ts.astype(np.float32)).astype(np.float32)
+            t = (t @ Rt.astype(np.float32).T + tt.astype(np.float32)).astype(np.float32)
+        out.append((s, t))
+    return out
+
+
+def probe_head(model, calib, dev, ridge=1.0):
+    """head_init 'probe': the output layer of the correspondence MLP (regtr.py:432-436, 3 x 256 + bias) fitted by ridge regression so that
+    the head predicts each token's OWN coordinates from the conditioned features of `calib` pairs (all six decoder layers, both clouds).
+    Why: the Kabsch covariance (se3_torch.py:108-154) is sum w (a - a_mean)(b - b_mean)^T over a = [src_kp ; tgt_corr], b = [src_corr ;
+    tgt_kp].  With a RANDOM output layer the predicted correspondences are spread over the object (singular values 6.7 / 5.0 / 3.4) but
+    UNCORRELATED with the key points (a linear fit explains 1.5 % of them): the covariance is a noise matrix, 0.020 / 0.011 / 0.0017, whose
+    condition number is an accident -- s1 / (s2 + s3) = 40 ... 380 on the ModelNet-size pairs, where the ORACLE's own float32 Kabsch is up to
+    1.1e-4 away from a float64 solve of the same inputs.  A trained head's predictions are a rigid image of the key points; the probe gives a
+    random-init network that property (r^2 ~ 0.3: the features carry the sine position embedding), the covariance becomes ~Var(kp), and
+    s1 / (s2 + s3) drops to 2 ... 11 on held-out pairs (float32-vs-float64 Kabsch 3e-7 ... 3e-6).  Everything upstream stays random-init."""
+    head = model.correspondence_decoder
+    with torch.no_grad():
+        out = model({'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in calib], 'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in calib]})
+        H, T = [], []
+        for side in ('src', 'tgt'):
+            for f, kp in zip(out[side + '_feat'], out[side + '_kp']):           # f (6, N, D), kp (N, 3)
+                h = torch.relu(torch.nn.functional.linear(f.reshape(-1, f.shape[-1]), head.coor_mlp[0].weight, head.coor_mlp[0].bias))
+                h = torch.relu(torch.nn.functional.linear(h, head.coor_mlp[2].weight, head.coor_mlp[2].bias))
+                H.append(h.double()); T.append(kp.expand(f.shape[0], -1, -1).reshape(-1, 3).double())
+        X = torch.cat(H); X = torch.cat([X, torch.ones_like(X[:, :1])], 1)
+        T = torch.cat(T)
+        sol = torch.linalg.solve(X.T @ X + ridge * torch.eye(X.shape[1], dtype=X.dtype, device=X.device), X.T @ T)     # (D + 1, 3)
+        head.coor_mlp[4].weight.copy_(sol[:-1].T.float())
+        head.coor_mlp[4].bias.copy_(sol[-1].float())
+        r2 = 1.0 - float(((X @ sol - T) ** 2).sum() / ((T - T.mean(0)) ** 2).sum())
+    return r2
+
+
+def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mode=False, first_id=None, distinct=None, real=False,
+                   head_init=None):
     """The benchmarked model and batch, exactly as the timed loop uses them (tests/test_gpu_bench_batch.py builds the same objects):
     conf/<config>.yaml architecture with torch.manual_seed(0) random-init weights, `n_pairs` deterministic synthetic pairs
     (ids rank * 100003 + i, or first_id + i) resident on `dev`.  config 'lomatch' = the 3dmatch pipeline on 10-30 %-overlap pairs.
+    real: the three shipped real 3DMatch pairs replicated under random rigid motions instead of synthetic rooms (real_pairs).
     distinct: generate only that many different pairs and cycle through them (setup time; nothing is cached between pairs).
+    head_init: 'uniform' (synthetic 3DMatch-size default) or 'probe' (ModelNet-size and real-fragment default) -- see below / probe_head.
     -> (cfg, model, pairs [(src, tgt) numpy], batch {'src_xyz': [...], 'tgt_xyz': [...]})"""
     from regtr_amd import RegTR, load_config
     cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{"3dmatch" if config == "lomatch" else config}.yaml'))
@@ -362,13 +441,22 @@ def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mo
     # meant to measure the kernels, so the benchmark draws that one 3 x 256 matrix from U(-0.5, 0.5) (as oracle/seeded_weights.py does
     # for the goldens): predictions spread over metres, the Procrustes problem is well conditioned and the 1e-4 bar on R|t means what
     # it says.  Still random-init weights; the throughput does not depend on their values.
+    # ModelNet-size pairs need more than spread (probe_head): there the output layer is a linear probe for the tokens' own coordinates.
+    head_init = head_init or ('probe' if (config == 'modelnet' or real) else 'uniform')      # (real fragments under the uniform layer: s1 / (s2 + s3) 30 - 60; probe: 1.5 - 5)
+    last = getattr(model.correspondence_decoder, 'coor_mlp', None)
     with torch.no_grad():
-        last = getattr(model.correspondence_decoder, 'coor_mlp', None)
         if last is not None:
             last[4].weight.uniform_(-0.5, 0.5)
+    if head_init == 'probe' and last is not None:
+        gen_c = synth_modelnet_pair if config == 'modelnet' else (lambda i: synth_pair(i, points, shuffle, overlap='lomatch' if config == 'lomatch' else None))
+        calib = real_pairs(4, 3) if real else [gen_c(900000 + i) for i in range(4)]       # calibration pairs: outside every benchmarked id range
+        model.head_probe_r2 = probe_head(model, calib, dev)
+    model.head_init = head_init
     base = rank * 100003 if first_id is None else first_id
     n_gen = n_pairs if not distinct else min(n_pairs, distinct)
-    if config == 'modelnet':
+    if real:
+        gen = real_pairs(n_gen, base)
+    elif config == 'modelnet':
         gen = [synth_modelnet_pair(base + i) for i in range(n_gen)]
     else:
         gen = [synth_pair(base + i, points, shuffle, overlap='lomatch' if config == 'lomatch' else None) for i in range(n_gen)]
@@ -489,7 +577,7 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     rank through ONE all_gather (regtr_amd/distributed.py) -- per pass over the set for lomatch, once at the end of the timed region
     otherwise.  step() -> (poses (n_local, 3, 4) of this rank's pairs, anything).  -> (elapsed s, all poses, all ids, last step's extra)"""
     from regtr_amd.distributed import gather_poses
-    n_set = args.total_pairs if lomatch else None        # (weak scaling: every rank holds the same count)
+    n_set = args.total_pairs if lomatch else int(pair_ids.numel()) * (dist.get_world_size() if dist else 1)      # (weak scaling: every rank holds the same count)
     gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids, n_set)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
     for _ in range(args.warmup):
         step()
@@ -562,13 +650,15 @@ def main():
     ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
+    ap.add_argument('--real', action='store_true', help='3dmatch: the three REAL pairs the reference ships (demo.py:26-49; tests/golden fixtures) replicated to --pairs under random rigid motions, instead of synthetic rooms')
+    ap.add_argument('--head-init', choices=['uniform', 'probe'], default=None, help="output layer of the correspondence head: U(-0.5, 0.5) (3dmatch default) or a linear probe for the tokens' coordinates (modelnet default): bench.probe_head")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-strict-f32', action='store_true', help="skip the side measurement of compute_dtype 'fp32x3' on the same workload")
     ap.add_argument('--no-range-check', action='store_true', help='diagnostic: cfg.f16_range_check off -- no status-word wait at the end of a forward, so consecutive forwards are enqueued back to back')
     ap.add_argument('--stub-backend', default=None, help=argparse.SUPPRESS)   # tests/test_bench_entry.py: 'gloo'
     ap.add_argument('--collect-pmc', action='store_true', help='run the rocprofv3 counter passes behind roofline.traffic on this workload and write profiles/pmc_traffic.json (stamped with the code version)')
-    ap.add_argument('--pmc-tag', default='r04', help=argparse.SUPPRESS)
+    ap.add_argument('--pmc-tag', default='r05', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-only', action='store_true',
                     help='no GPU needed: time only the CPU baseline leg on the synthetic workload and print it (where /root/reference '
                          'exists this times the REAL reference module, kind "reference")')
@@ -621,8 +711,10 @@ def main():
     dtype = args.dtype or ('bf16' if args.config == 'modelnet' else 'fp32')
     lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, dev)
     n_local = int(pair_ids.numel())
+    if args.real and args.config != '3dmatch':
+        sys.exit('bench.py: --real is the 3dmatch configuration on the shipped real fragments')
     cfg, model, pairs, batch = build_workload(args.config, n_local, args.points, args.shuffle, rank, dev, dtype, args.parity_mode,
-                                              distinct=args.distinct_pairs if lomatch else None)
+                                              distinct=args.distinct_pairs if lomatch else None, real=args.real, head_init=args.head_init)
     if args.no_range_check:
         model._range_check = False
 
@@ -654,6 +746,11 @@ def main():
                 workload = (f'BASELINE configs[3]: {args.total_pairs} 3DLoMatch-like pairs (overlap 10-30 %) sharded pair i -> rank i % {world}, '
                             f'{per_fwd} pairs per forward, one RCCL pose all_gather per pass; a step = one pass over the set '
                             f'({min(args.distinct_pairs, n_local)} distinct synthetic pairs per rank, cycled)')
+            if args.real:
+                metric = 'point-cloud pairs/sec (3DMatch REAL fragments, ~17-25k pts)'
+                workload = ('BASELINE configs[2] on REAL data: the three 3DMatch pairs the reference ships (demo.py:26-49: red-kitchen, hotel_umd, '
+                            f'home_at) replicated to {args.pairs} per forward, every replica under its own random rigid motions (rot <= 45 deg, |t| <= 0.5 m); '
+                            'full KPConv encoder + 6-layer cross-attn + SVD')
             if args.parity_mode:
                 workload += ' [PARITY MODE: reference row / tie orders reproduced on the GPU]'
         res = {
@@ -661,9 +758,10 @@ def main():
             'n_gpus': ranks_seen, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'per_rank_ms_per_step': [round(t / args.steps * 1e3, 3) for t in per_rank],
             'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None,
-            'dtype': {'fp32': 'f32 (f16-pair split, 22-bit operands)', 'fp32x3': 'f32 (bf16x3 split, 24-bit operands)'}.get(dtype, dtype), 'data': 'synthetic',
+            'dtype': {'fp32': 'f32 (f16-pair split, 22-bit operands)', 'fp32x3': 'f32 (bf16x3 split, 24-bit operands)'}.get(dtype, dtype),
+            'data': 'real 3DMatch fragments (3 shipped pairs, replicated under random rigid motions)' if args.real else 'synthetic',
             'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
-                       'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights (head output layer U(-0.5, 0.5): a well-conditioned Procrustes problem)', 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
+                       'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights; head output layer: ' + ('U(-0.5, 0.5) (predictions spread over metres: a well-conditioned Procrustes problem)' if model.head_init == 'uniform' else f"linear probe for the tokens' own coordinates fitted on 4 calibration pairs (r^2 {model.head_probe_r2:.2f}; bench.probe_head: correspondences correlated with the key points, as a trained head's are -- a well-conditioned Procrustes problem)"), 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
                        'parallelism': f'pair-sharded x{world}, ONE RCCL all_gather_into_tensor of the (pose | id) rows', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
                        'arithmetic': {'fp32': 'float32-grade: exact operand splits on the 16-bit matrix cores (f16 pair, three MFMA terms, where the strip GEMM / attention '
                                               'kernels serve the shape; bf16x3, six terms, elsewhere), float32 accumulation; exact-f32 MFMA in the KPConv gather',
@@ -680,7 +778,7 @@ def main():
         fwd_batch = {k: v[chunks[0][0]:chunks[0][1]] for k, v in batch.items()}
         if not args.no_roofline:
             r = measure_kpconv_roofline(model, fwd_batch)
-            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r) if (args.config == '3dmatch' and not args.parity_mode) else None
+            traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r, args.real) if (args.config == '3dmatch' and not args.parity_mode) else None
             gather = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
             if gather['frac'] > 1.0:      # small clouds (ModelNet-size): the gathered rows never leave L2 / Infinity Cache
@@ -698,6 +796,9 @@ def main():
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
             res['roofline_gemm'] = measure_gemm_roofline(model, fwd_batch)
+            res['preprocess'] = measure_preprocess(model, fwd_batch)
+            # the candid companion of roofline.frac, at the top level: HBM bytes the COUNTERS saw per gather launch / launch time / peak
+            res['counter_hbm_frac_of_peak'] = r.get('counter_hbm_frac_of_peak')
         if dtype not in ('fp32', 'fp32x3'):
             # reduced-precision error, reported next to the number (parity is gated in fp32): same batch, float32-grade model
             from regtr_amd import RegTR, load_config
@@ -727,12 +828,24 @@ def main():
             for _ in range(k3):
                 o3 = m3(dict(fwd_batch))
             torch.cuda.synchronize(); t3 = (time.perf_counter() - t3) / k3
+            res['fp32x3_pairs_per_s'] = len(fwd_batch['src_xyz']) / t3      # strictly 24-bit operands, same weights and batch, this run
             res['config']['fp32x3_same_workload'] = {'value': len(fwd_batch['src_xyz']) / t3, 'unit': 'pairs/s', 'ms_per_step': t3 * 1e3, 'steps': k3,
                                                      'max_abs_pose_vs_default': float((o3['pose'] - model(dict(fwd_batch))['pose']).abs().max())}
             del m3
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
             res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(24 if args.config == 'modelnet' else 6)],
                                                cfg_name='3dmatch' if lomatch else args.config)
+            # the REAL reference module cannot run on a GPU box (no /root/reference there): its rate on the same synthetic workload, measured
+            # in the build container (`python bench.py --cpu-baseline-only`), travels as a committed profile and is quoted beside the port
+            try:
+                ref_file = os.path.join(ROOT, 'profiles', f'r02_cpu_baseline_reference_{"modelnet" if args.config == "modelnet" else "3dmatch"}.json')
+                rb = json.load(open(ref_file))['cpu_baseline']
+                res['cpu_baseline']['reference_module_build_container'] = {
+                    'value': rb['value'], 'unit': rb['unit'], 'cores': rb['cores'], 'kind': rb['kind'], 'sample': rb['sample'],
+                    'source': os.path.relpath(ref_file, ROOT), 'note': 'a different host (the 8-core build container), not this box: never to be '
+                    'compared with `value` as a speed-up of one over the other'}
+            except (OSError, KeyError, ValueError):
+                pass
         print(json.dumps(res))
     if dist:
         dist.barrier()

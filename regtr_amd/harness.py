@@ -278,23 +278,32 @@ class Prefetcher:
 #     128 small ones, and hands the consumer per-cloud VIEWS of that one device buffer; the consumer stream waits on the copy's event.
 # Measured on the 16-core-quota GPU boxes (profiles/r04_*_e2e_harness.txt): more than ~6 loader processes slow the set down (they compete
 # with the launching thread for the quota), hence the default of 4.
-_POOL_SOURCE = None          # the pair source of this process's loader workers (set before the fork)
-_POOL_SLABS = None           # slab id -> numpy view of the shared slab (inherited by the fork)
+_POOL_SLABS = {}             # pool id -> [numpy views of the pool's shared slabs]; set before the fork and kept until close(), so that a
+#                              worker multiprocessing.Pool re-spawns later (forked from the parent THEN) finds them too
+_POOL_SOURCES = {}           # (worker side) source file -> unpickled pair source, loaded once per worker
 _PINNED = {}                 # (device, points) -> two page-locked staging buffers, kept for the life of the process
+_POOL_IDS = [0]
 
 
 def _pool_fill(task):
     """Runs in a loader process: loads the pairs `idxs` (one PART of a batch) and packs them into its region [lo, lo + cap) of slab
     `slab_id` as [src clouds ..., tgt clouds ...].  -> (b, part, lens_src, lens_tgt, ids, None) or, when the part does not fit its
     region, (b, part, None, None, ids, (src arrays, tgt arrays)) with the clouds pickled back (correct, slower)."""
-    b, part, idxs, slab_id, lo, cap = task
-    items = [_POOL_SOURCE[i] for i in idxs]
+    b, part, idxs, slab_id, lo, cap, pool_id, source_file = task
+    source = _POOL_SOURCES.get(source_file)
+    if source is None:        # first task of this worker (or of a re-spawned one): the pair source arrives by file, not by fork
+        import pickle
+        with open(source_file, 'rb') as f:
+            source = pickle.load(f)
+        _POOL_SOURCES.clear()
+        _POOL_SOURCES[source_file] = source
+    items = [source[i] for i in idxs]
     src, tgt = [it['src_xyz'] for it in items], [it['tgt_xyz'] for it in items]
     ls, lt = [int(c.shape[0]) for c in src], [int(c.shape[0]) for c in tgt]
     ids = [int(it['idx']) for it in items]
     if sum(ls) + sum(lt) > cap:
         return b, part, None, None, ids, ([np.ascontiguousarray(c, dtype=np.float32) for c in src], [np.ascontiguousarray(c, dtype=np.float32) for c in tgt])
-    slab = _POOL_SLABS[slab_id]
+    slab = _POOL_SLABS[pool_id][slab_id]
     o = lo
     for c, n in zip(src + tgt, ls + lt):
         slab[o:o + n] = c
@@ -305,14 +314,16 @@ def _pool_fill(task):
 class LoaderPool:
     """`workers` forked loader processes + their shared slabs over one pair source; `iterate(indices, batch)` yields batches
     {'src_xyz': [...], 'tgt_xyz': [...], 'ids': [...]} of device tensors (CPU tensors for a cpu `device`: the tests' path), in order.
-    The pool outlives a pass: create it once (before the GPU is initialised, if possible: forking a process that holds a HIP context
-    copies far more page tables), iterate as often as needed, close() at the end.  slab_points: capacity of a slab in points (default
-    1.25 x max_batch x 2 x 24k; a batch that does not fit comes back pickled -- correct, slower)."""
+    The pool outlives a pass: create it once, iterate as often as needed, close() at the end.  It can (and test.py does) be created
+    BEFORE the GPU is initialised and before torch.distributed -- forking a process that holds a HIP context / a process group copies that
+    state into every worker: the constructor touches no GPU API, the pair source may be handed over later (`set_source`, by a pickle file:
+    workers -- including ones multiprocessing re-spawns -- load it on their first task) and the page-locked staging buffers are made by
+    `prepare()` / the first pass.  slab_points: capacity of a slab in points (default 1.25 x max_batch x 2 x 24k; a batch that does not
+    fit comes back pickled -- correct, slower)."""
 
-    def __init__(self, pairs, device, workers=4, max_batch=64, depth=None, slab_points=None):
+    def __init__(self, pairs, device, workers=4, max_batch=64, depth=None, slab_points=None, maxtasksperchild=None):
         import mmap
         import multiprocessing as mp
-        global _POOL_SOURCE, _POOL_SLABS
         self.device = torch.device(device)
         self.workers = max(1, int(workers))
         self.cuda = self.device.type == 'cuda'
@@ -320,13 +331,40 @@ class LoaderPool:
         n_slabs = depth or (self.workers + 2)
         self._maps = [mmap.mmap(-1, self.cap * 12) for _ in range(n_slabs)]           # MAP_SHARED | MAP_ANONYMOUS: inherited by the fork
         self.slabs = [np.frombuffer(m, dtype=np.float32).reshape(self.cap, 3) for m in self._maps]
-        _POOL_SOURCE, _POOL_SLABS = pairs, self.slabs
-        self.pool = mp.get_context('fork').Pool(self.workers)
-        _POOL_SOURCE = None
+        _POOL_IDS[0] += 1
+        self.pool_id = _POOL_IDS[0]
+        _POOL_SLABS[self.pool_id] = self.slabs          # stays registered until close(): re-spawned workers inherit it as well
+        self.pool = mp.get_context('fork').Pool(self.workers, maxtasksperchild=maxtasksperchild)
+        self._source_file = None
         self.copy_stream = None
         self.last_timing = None
+        if pairs is not None:
+            self.set_source(pairs)
+        if self.cuda and torch.cuda.is_initialized():
+            self.prepare()
+
+    def set_source(self, pairs):
+        """The pair source the workers index (`pairs[i]` -> {'src_xyz', 'tgt_xyz', 'idx', ...}); must pickle."""
+        import pickle
+        import tempfile
+        self._drop_source_file()
+        fd, self._source_file = tempfile.mkstemp(prefix='regtr_pairs_', suffix='.pkl')
+        with os.fdopen(fd, 'wb') as f:
+            pickle.dump(pairs, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    def _drop_source_file(self):
+        if self._source_file is not None:
+            try:
+                os.unlink(self._source_file)
+            except OSError:
+                pass
+            self._source_file = None
+
+    def prepare(self):
+        """Page-locks the two staging buffers (tens of ms: not inside the first timed pass).  Needs the GPU runtime, so call it after
+        torch.cuda.set_device when the pool was created before."""
         if self.cuda:
-            self._staging()                  # (page-locking 2 x cap x 12 bytes takes tens of ms: not inside the first pass)
+            self._staging()
 
     def _staging(self):
         key = (str(self.device), self.cap)
@@ -342,9 +380,13 @@ class LoaderPool:
             free.put(sid)
         if self.cuda and self.copy_stream is None:
             self.copy_stream = torch.cuda.Stream(device=self.device)
+        if self._source_file is None:
+            raise RuntimeError('LoaderPool.iterate: no pair source (set_source)')
         import sys
-        if sys.getswitchinterval() > 0.0005:
-            sys.setswitchinterval(0.0005)    # the launching thread shares the interpreter with the two loader threads below: short GIL hand-offs
+        interval = sys.getswitchinterval()
+        if interval > 0.0005:
+            sys.setswitchinterval(0.0005)    # the launching thread shares the interpreter with the two loader threads below: short GIL
+        #                                      hand-offs for the duration of the pass (restored when the generator finishes)
         stage = self._staging() if self.cuda else None
         timing = {'wait_worker_s': 0.0, 'stage_copy_s': 0.0, 'h2d_wait_s': 0.0, 'batches': n_batches}
         self.last_timing = timing
@@ -361,7 +403,8 @@ class LoaderPool:
                     sid = free.get()
                     idxs = indices[b * batch:(b + 1) * batch]
                     per = (len(idxs) + parts - 1) // parts
-                    tasks = [(b, p, idxs[p * per:(p + 1) * per], sid, p * region, region) for p in range(parts) if idxs[p * per:(p + 1) * per]]
+                    tasks = [(b, p, idxs[p * per:(p + 1) * per], sid, p * region, region, self.pool_id, self._source_file)
+                             for p in range(parts) if idxs[p * per:(p + 1) * per]]
                     pending.put((sid, [self.pool.apply_async(_pool_fill, (t,)) for t in tasks]))
                 pending.put(None)
             except BaseException as e:      # noqa: BLE001
@@ -439,24 +482,29 @@ class LoaderPool:
 
         threading.Thread(target=dispatch, daemon=True).start()
         threading.Thread(target=upload, daemon=True).start()
-        while True:
-            t0 = time.perf_counter()
-            b = out.get()
-            timing['h2d_wait_s'] += time.perf_counter() - t0      # (time the CONSUMER stood waiting for a batch)
-            if b is None:
-                return
-            if isinstance(b, BaseException):
-                raise b
-            if self.cuda:
-                cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(b['ready'])
-                b['dev'].record_stream(cur)                 # allocated on the copy stream, consumed here
-            yield b
+        try:
+            while True:
+                t0 = time.perf_counter()
+                b = out.get()
+                timing['h2d_wait_s'] += time.perf_counter() - t0      # (time the CONSUMER stood waiting for a batch)
+                if b is None:
+                    return
+                if isinstance(b, BaseException):
+                    raise b
+                if self.cuda:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(b['ready'])
+                    b['dev'].record_stream(cur)                 # allocated on the copy stream, consumed here
+                yield b
+        finally:
+            sys.setswitchinterval(interval)                     # the process-wide switch interval is the caller's again
 
     def close(self):
         if self.pool is not None:
             self.pool.terminate(); self.pool.join()
             self.pool = None
+        _POOL_SLABS.pop(self.pool_id, None)
+        self._drop_source_file()
         self.slabs = []
         for m in self._maps:
             try:

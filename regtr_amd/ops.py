@@ -388,9 +388,19 @@ def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_o
     KP = kernel_points.shape[0]
     wf = torch.empty((nq, 16), dtype=torch.float32, device=x.device)
     num = torch.empty(nq, dtype=torch.float32, device=x.device)
+    rec = context.current().gather_records           # bench.py's roofline: this gather is one of a forward's KPConv gather launches too
+    if rec is not None:
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
     check(L.regtr_kpconv_gather(ptr(q_xyz), nq, ptr(s_xyz), ns, iptr(nbr), H, ptr(x), 1, None, ptr(xyzf), ptr(kernel_points), KP,
                                 float(extent), None, None, 0, slope, ptr(wf), 16, ptr(num), stream()), 'regtr_kpconv_gather')
-    return _block_tail(wf, None, num, None, w16_kn, None, seg_off, max_len, slope, eps, want_stats)
+    if rec is not None:
+        e1.record()
+    res = _block_tail(wf, None, num, None, w16_kn, None, seg_off, max_len, slope, eps, want_stats)
+    if rec is not None:
+        e2.record()
+        rec.append((e0, e1, e2, nq, H, 1, w16_kn.shape[1]))
+    return res
 
 
 STREAM_MIN_ROWS = 131072     # below this a forward is launch-bound (a pair or two): the tiled kernels and separate passes are as fast

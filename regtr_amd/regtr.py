@@ -11,6 +11,7 @@ sizes after preprocessing): preprocess -> KPConv encoder -> feat_proj -> 6 cross
 correspondence head -> fused weighted-Procrustes.
 """
 import logging
+import threading
 
 import torch
 import torch.nn as nn
@@ -92,6 +93,11 @@ class CorrespondenceDecoder(nn.Module):
         return corr, logit.view(Lyr, N)
 
 
+def _throttled(n):
+    """Log occurrence no. n?  The first three, then every power of two: a permanent condition stays visible without flooding the log."""
+    return n <= 3 or (n & (n - 1)) == 0
+
+
 class _LossParams(nn.Module):
     """Holds InfoNCELossFull.W (feature_loss.py:261) so reference checkpoints load strictly; never used at inference."""
 
@@ -140,6 +146,7 @@ class RegTR(nn.Module):
         self._f16_pair = dt in ('fp32', 'bf16') and ops.f16_pair_default      # ('bf16': the encoder / head GEMMs, which stay float32-grade)
         self._range_check = bool(cfg.get('f16_range_check', True))
         self.f16_range_fallbacks = 0          # forwards re-run in fp32x3 arithmetic because an f16 pair operand left the format's range
+        self.nonfinite_pose_forwards = 0      # forwards whose pose came out non-finite with every f16 pair product finite (bad inputs / weights)
         self.transformer_encoder = TransformerCrossEncoder(encoder_layer, cfg.num_encoder_layers, encoder_norm,
                                                            return_intermediate=True)
         if cfg.get('direct_regress_coor', False):                                 # :68-73
@@ -162,9 +169,17 @@ class RegTR(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _status_word(self, dev):
-        """(device int32[1], pinned host int32[1]) of this model on `dev`: the status word the kernels of a forward OR bits into."""
-        return _prepared(self._cache, ('status', dev), self.feat_proj.bias,
-                         lambda _: (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory()))
+        """(device int32[1], pinned host int32[1]) the kernels of ONE forward OR bits into.  One pair per (host thread, HIP stream): two
+        threads -- or two streams -- driving the SAME model each zero, fill and read their own word, so one forward can neither erase nor
+        steal another's overflow bit (a forward is complete on its stream before the next one on that stream zeroes the word)."""
+        key = ('status', dev, threading.get_ident(), _lib.stream())
+        ent = self._cache.get(key)
+        if ent is None:
+            if sum(1 for k in self._cache if isinstance(k, tuple) and k and k[0] == 'status') > 64:       # dead threads / streams
+                for k in [k for k in self._cache if isinstance(k, tuple) and k and k[0] == 'status']:
+                    del self._cache[k]
+            ent = self._cache[key] = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory())
+        return ent
 
     def _side_stream(self, dev):
         return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
@@ -197,10 +212,11 @@ class RegTR(nn.Module):
         # kernels go to torch's current stream of the CURRENT device: the context makes the tensors' device current for the whole
         # forward and carries the operand format / status word to every launch (thread-local: regtr_amd/context.py)
         check = self._f16_pair and self._range_check
-        st_dev, st_host = self._status_word(dev) if check else (None, None)
-        with context.forward(dev, f16_pair=self._f16_pair, status=st_dev):
+        with context.forward(dev, f16_pair=self._f16_pair, status=None) as ctx:
             if not check:
                 return self._forward(batch, dev)
+            st_dev, st_host = self._status_word(dev)         # (inside the context: the launch device is current, the stream is this thread's)
+            ctx.status = st_dev
             st_dev.zero_()
             out = self._forward(batch, dev)
             st_host.copy_(st_dev, non_blocking=True)
@@ -210,13 +226,21 @@ class RegTR(nn.Module):
             bits = int(st_host[0])
         if bits == 0:
             return out
-        # an operand left f16's range (or the pose came out non-finite): the same forward in fp32x3 arithmetic -- float32's range
+        if not bits & context.STATUS_F16_RANGE:
+            # only the pose is non-finite: the f16 pair products were all finite, so the arithmetic is not the cause -- a NaN / Inf in the
+            # input clouds or the weights, or a degenerate pair.  A re-run in fp32x3 would return the same NaN at twice the cost.
+            self.nonfinite_pose_forwards += 1
+            if _throttled(self.nonfinite_pose_forwards):
+                self.logger.warning('non-finite pose in the output (status %d; forward no. %d with this condition): every f16 pair product was '
+                                    'finite, so check the input clouds and the checkpoint for NaN / Inf -- returned as is, not re-run',
+                                    bits, self.nonfinite_pose_forwards)
+            return out
+        # an operand left f16's range: the same forward in fp32x3 arithmetic -- float32's range
         self.f16_range_fallbacks += 1
-        if self.f16_range_fallbacks <= 3:
-            self.logger.warning('f16 pair operand range exceeded (status %d: %s) -- forward re-run with six-term bf16 splits '
-                                "(compute_dtype 'fp32x3' arithmetic); set cfg.compute_dtype: fp32x3 to skip the first attempt", bits,
-                                ' + '.join(n for b, n in ((context.STATUS_F16_RANGE, 'non-finite f16 pair product'),
-                                                          (context.STATUS_NONFINITE_POSE, 'non-finite pose')) if bits & b))
+        if _throttled(self.f16_range_fallbacks):
+            self.logger.warning('f16 pair operand range exceeded (status %d; fallback no. %d) -- forward re-run with six-term bf16 splits '
+                                "(compute_dtype 'fp32x3' arithmetic, twice the cost of this forward); set cfg.compute_dtype: fp32x3 to skip "
+                                'the first attempt', bits, self.f16_range_fallbacks)
         with context.forward(dev, f16_pair=False, force_x3=True, status=None):
             return self._forward(batch, dev)
 

@@ -36,7 +36,8 @@ parser.add_argument('--dev', action='store_true', help='If true, will ignore log
 parser.add_argument('--name', type=str, help='Prefix to add to logging directory')
 parser.add_argument('--num_workers', type=int, default=-1,
                     help='loader PROCESSES (reference test.py:26; there one pair per step, here each assembles whole batches into pinned slabs: '
-                         'regtr_amd/harness.py BatchLoader); 0 = one loader thread in this process; default -1 = min(8, usable cores)')
+                         'regtr_amd/harness.py LoaderPool); 0 = one loader thread in this process; default -1 = 4 (more than ~6 compete with the launching '
+                         'thread for a 16-core quota and slow the set down)')
 parser.add_argument('--resume', type=str, help='Checkpoint to resume from')
 # harness options (not in the reference)
 parser.add_argument('--batch', type=int, default=64,
@@ -137,6 +138,11 @@ def main():
         logger.error('regtr_amd runs on an MI355X (HIP) device only; there is no CPU path')
         sys.exit(-3)
     device = torch.device('cuda', local_rank)
+    # loader processes: forked HERE -- before this process holds a HIP context (torch.cuda.is_available() only counts devices), before the
+    # optional pool reservation, before torch.distributed and before the model exists, so the workers inherit none of that.  They sit
+    # idle until run_test hands them batches (nothing is read ahead of the timed loop); the pair source reaches them by file later.
+    workers = opt.num_workers if opt.num_workers >= 0 else 4
+    pool = harness.LoaderPool(None, device, workers=workers, max_batch=opt.batch) if workers > 0 else None
     torch.cuda.set_device(device)
     if opt.alloc_conf:
         torch.cuda.memory._set_allocator_settings(opt.alloc_conf)
@@ -172,10 +178,9 @@ def main():
         logger.error('ModelNet h5 loading is not part of the inference hot path here (h5py is not a dependency); use --synthetic N')
         sys.exit(-4)
 
-    # loader processes: forked BEFORE the model exists (a process that holds a HIP context and the weights is slower to fork); they
-    # sit idle until run_test hands them batches -- nothing is read ahead of the timed loop
-    workers = opt.num_workers if opt.num_workers >= 0 else 4
-    pool = harness.LoaderPool(pairs, device, workers=workers, max_batch=opt.batch) if workers > 0 else None
+    if pool is not None:
+        pool.set_source(pairs)           # (a pickle file the workers load on their first task)
+        pool.prepare()                   # page-locked staging buffers, outside the timed loop
 
     model = RegTR(cfg).to(device)
     if opt.resume:

@@ -40,6 +40,17 @@ def test_lomatch_set_is_sharded_and_gathered_every_pass():
     assert d['n_gpus'] == 2 and d['pairs_per_step'] == 23 and d['forwards_per_step_rank0'] == 3 and d['scaling'] == 'strong'
 
 
+def test_lomatch_1781_pairs_on_eight_ranks():
+    """The world-8 rehearsal of configs[3] that needs no 8-GPU node: `bench.py --gpus 8 --config lomatch --total-pairs 1781` on gloo with the
+    stand-in forward -- 223 / 222-row shards (ragged), 64 per forward (4 forwards per pass on every rank, the last one ragged), every pose
+    on every rank in pair order after each pass (asserted inside run_stub), eight ranks seen through the gather."""
+    r = _run(['--gpus', '8', '--config', 'lomatch', '--total-pairs', '1781', '--steps', '2', '--warmup', '1', '--stub-backend', 'gloo'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['n_gpus'] == 8 and d['pairs_per_step'] == 1781 and d['forwards_per_step_rank0'] == 4 and d['scaling'] == 'strong'
+    assert len(d['per_rank_ms_per_step']) == 8
+
+
 def test_parity_check_logic_on_cpu():
     """bench.parity_check (the "pose err vs ref" field of the bench line) on a stand-in product: the oracle's own batched forward must
     pass with zero error, a 1e-3 shift of one correspondence row must fail the gate, a broken key point must fail bit-exactness."""

@@ -75,6 +75,34 @@ def test_batch_loader_processes_and_npy_cache(tmp_path):
     assert np.array_equal(ds[0]['src_xyz'], new)
 
 
+def test_loader_pool_forked_before_the_source_and_respawned_workers(tmp_path):
+    """test.py forks the loader processes before the GPU runtime, torch.distributed and the pair source exist: the source reaches the
+    workers by file (LoaderPool.set_source), so a worker multiprocessing.Pool RE-SPAWNS later (forked from the parent long after the
+    constructor) serves tasks like the original ones; iterate() leaves the process-wide switch interval as it found it."""
+    import sys
+    from regtr_amd import harness
+    # maxtasksperchild=1: every worker exits after one task and multiprocessing forks a replacement from the parent AS IT IS THEN
+    pool = harness.LoaderPool(None, torch.device('cpu'), workers=2, max_batch=3, maxtasksperchild=1)      # no source yet
+    with pytest.raises(RuntimeError, match='no pair source'):
+        next(pool.iterate([0], 1))
+    info = harness.materialize_synthetic(str(tmp_path / 'data'), 5, points=1200)
+    ds = harness.ThreeDMatchPairs(info, str(tmp_path / 'data'))
+    pool.set_source(ds)
+    interval = sys.getswitchinterval()
+    first = {w.pid for w in pool.pool._pool}
+    for _ in range(3):
+        seen = []
+        for b in pool.iterate(list(range(5)), 2):
+            for k, i in enumerate(b['ids']):
+                assert np.array_equal(b['src_xyz'][k].numpy(), ds[i]['src_xyz'])
+            seen += b['ids']
+        assert seen == list(range(5)) and sys.getswitchinterval() == interval
+    assert not ({w.pid for w in pool.pool._pool} & first)          # the original workers are gone: re-spawned ones served the later passes
+    src_file = pool._source_file
+    pool.close()
+    assert not os.path.exists(src_file)
+
+
 def test_est_log_format(tmp_path):
     """Block layout of generic_reg_model.py:276-281: 'tgt\\tsrc\\t-1' then four tab-separated rows with 12 decimals."""
     from regtr_amd.harness import write_est_log
