@@ -29,6 +29,7 @@
  *   regtr_gemm_stream         nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
  *   regtr_block_tail          ResnetBottleneckBlock tail (unary2 + unary_shortcut + sum + LeakyReLU), SimpleBlock after its gather
  *                                                                 kpconv_blocks.py:727-741, 590-646
+ *   regtr_encoder_fwd         KPFEncoder.forward (blocks sequenced) models/backbone_kpconv/kpconv.py:81-88, kpconv_blocks.py:632-646,706-741
  *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
  *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
  *   regtr_mha_fwd             nn.MultiheadAttention core          transformers.py:197-226
@@ -53,7 +54,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 9
+#define REGTR_ABI_VERSION 10
 int regtr_abi_version(void);
 
 /* The STATUS WORD: an optional device int (zeroed by the caller, e.g. once per forward) that kernels OR bits into -- conditions that
@@ -315,6 +316,51 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
                             const float* final_beta, float final_eps, int return_intermediate, const float* pe,
                             const int* seg_off, const int* kv_self, const int* kv_cross, int n_clouds, int max_len,
                             int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, int* status, void* stream);
+
+/* The KPConv encoder's blocks (kpconv.py:81-88 KPFEncoder.forward over kpconv_blocks.py:632-646 SimpleBlock.forward and :706-741
+ * ResnetBottleneckBlock.forward) enqueued by ONE call, for the SMALL-batch regime: a pair or two per forward -- the reference's own
+ * operating mode (conf/3dmatch.yaml:11 test_batch_size 1, trainer.py:202-206), where the host, not the GPU, bounds an op-by-op forward.
+ * The same launches, with the same arguments, in the same order as regtr_amd/kpconv.py issues them through the entry points above
+ * (outputs bit-identical); intermediates carved from one workspace.  HOST-side descriptors: */
+typedef struct {
+    const float* kn;        /* [K, N] float32 row-major (regtr_gemm_f32's B) */
+    const void* planes;     /* regtr_gemm_split_weights of the matrix, or NULL (shape not served by regtr_gemm_x3) */
+    const void* planes16;   /* regtr_gemm_split_weights_f16, or NULL (a weight beyond the f16 range: stays on `planes`) */
+    int N, K;               /* N == 0: no such Linear in the block (identity) */
+} regtr_weight_t;
+typedef struct {
+    int kind;               /* 0 SimpleBlock, 1 ResnetBottleneckBlock */
+    int strided;            /* 1: the convolution reads level `layer` and writes level `layer + 1` (pool table, max-pooled shortcut) */
+    int layer;
+    int n_kp;               /* kernel points (<= 16) */
+    float extent;           /* KP_extent of the block's KPConv */
+    const float* kernel_points;     /* [n_kp, 3] */
+    regtr_weight_t unary1;  /* kind 1: Linear in front of the KPConv (N == 0: nn.Identity) */
+    regtr_weight_t conv;    /* KPConv.weights viewed as [n_kp * Cin, Cout] */
+    regtr_weight_t unary2;  /* kind 1 */
+    regtr_weight_t shortcut;        /* kind 1: unary_shortcut (N == 0: nn.Identity) */
+} regtr_encoder_block_t;
+typedef struct {
+    const float* points;    /* [n, 3] */
+    int n;                  /* live rows of the level (host-known: the one read-back of a forward) */
+    const int* conv_idx;    /* [n, K] neighbour table of the level, or NULL */
+    const int* pool_idx;    /* [n of the NEXT level, K] supports of this level per next-level point, or NULL */
+    int K;                  /* columns of both tables */
+    int pool_width;         /* columns of pool_idx the strided shortcut's max-pool reads (K; the parity mode's narrower CPU tables) */
+    const int* seg_off;     /* [n_clouds + 1] */
+    int max_len;            /* longest cloud of the level */
+} regtr_encoder_level_t;
+/* supported(): the regime (fewer than 65536 level-0 rows: none of the large-batch kernel forms applies) and the shapes; otherwise issue
+ * the launches one by one.  x_in [rows of block `first`'s level, its input width] -> out [rows of block `last - 1`'s level, its width];
+ * blocks [first, last).  f16_pair: contractions in the f16 pair format where planes16 exists and the kernel serves the shape (what
+ * cfg.compute_dtype 'fp32' runs); ws: regtr_encoder_ws_bytes(...) bytes for the same arguments. */
+int regtr_encoder_supported(const regtr_encoder_block_t* blocks, int n_blocks, const regtr_encoder_level_t* levels, int n_levels,
+                            int n_clouds, int first, int last);
+size_t regtr_encoder_ws_bytes(const regtr_encoder_block_t* blocks, int n_blocks, const regtr_encoder_level_t* levels, int n_levels,
+                              int n_clouds, int first, int last, int f16_pair);
+int regtr_encoder_fwd(const regtr_encoder_block_t* blocks, int n_blocks, const regtr_encoder_level_t* levels, int n_levels, int n_clouds,
+                      int first, int last, const float* x_in, float* out, int f16_pair, float slope, float eps, void* ws, size_t ws_bytes,
+                      int* status, void* stream);
 
 /* CorrespondenceDecoder.simple_attention (regtr.py:316-351, `direct_regress_coor: False`): single-head attention whose values
  * are coordinates.  q, k [n_layers, n_total, head_dim] contiguous (projections of the conditioned features), xyz [n_total,3],

@@ -22,8 +22,24 @@ _I = _c.c_int
 _F = _c.c_float
 _Z = _c.c_size_t
 
+class Weight(_c.Structure):
+    """regtr_weight_t (include/regtr_hip.h)."""
+    _fields_ = [('kn', _P), ('planes', _P), ('planes16', _P), ('N', _I), ('K', _I)]
+
+
+class EncoderBlock(_c.Structure):
+    """regtr_encoder_block_t."""
+    _fields_ = [('kind', _I), ('strided', _I), ('layer', _I), ('n_kp', _I), ('extent', _F), ('kernel_points', _P),
+                ('unary1', Weight), ('conv', Weight), ('unary2', Weight), ('shortcut', Weight)]
+
+
+class EncoderLevel(_c.Structure):
+    """regtr_encoder_level_t."""
+    _fields_ = [('points', _P), ('n', _I), ('conv_idx', _P), ('pool_idx', _P), ('K', _I), ('pool_width', _I), ('seg_off', _P), ('max_len', _I)]
+
+
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 9          # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 10         # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -77,9 +93,14 @@ SIGNATURES = {
     'regtr_cross_encoder_supported': (_I, [_I, _I, _I, _I]),
     'regtr_cross_encoder_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_cross_encoder_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
+    'regtr_encoder_supported': (_I, [_P, _I, _P, _I, _I, _I, _I]),
+    'regtr_encoder_ws_bytes': (_Z, [_P, _I, _P, _I, _I, _I, _I, _I]),
+    'regtr_encoder_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _F, _P, _Z, _P, _P]),
     'regtr_attn_xyz': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
+
+COMPOSITE = ('regtr_encoder_fwd', 'regtr_cross_encoder_fwd')      # bound through a GIL-releasing handle (see _load)
 
 _ERR = {-1: 'kernel launch failed', -2: 'invalid argument', -3: 'workspace too small'}
 
@@ -111,6 +132,14 @@ def _load():
             fn = getattr(_lib, name)
             fn.restype = res
             fn.argtypes = args
+        # ... except the COMPOSITE entry points, which enqueue ~70-130 launches per call (0.3-0.5 ms inside the library, and hipLaunchKernel
+        # can block on queue back-pressure): those release the GIL (a CDLL handle of the same library), so a loader / upload thread or a
+        # second model's thread is not frozen for the duration.  The trade-off for the short calls stays as described above.
+        nogil = ctypes.CDLL(LIB_PATH)
+        for name in COMPOSITE:
+            fn = getattr(nogil, name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
+            setattr(_lib, name, fn)
         got = _lib.regtr_abi_version()
         if got != ABI_VERSION:
             _lib = None

@@ -58,20 +58,36 @@ __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* _
         mu[c] = 0.f; rs[c] = 1.f;
         if (INFOLD) { const float2 s = stats[(size_t)cloud * K + 32 * c + chc]; mu[c] = s.x; rs[c] = s.y; }
     }
-    // The moments are those of x - pivot, pivot = the cloud's FIRST row (every wave and chunk of the cloud loads the same one):
-    // covariances do not change under a shift, and the float32 rounding of the sums (~1e-6 of sum x^2) then scales with the spread
-    // of a channel instead of with its mean^2 -- a near-constant channel (variance << mean^2) would otherwise lose its variance
-    // to that rounding.  k_tail_prepare adds the pivot back to the means.
+    // The moments are those of x - pivot: covariances do not change under a shift, and the float32 rounding of the sums (~1e-6 of
+    // sum x^2) then scales with (spread + |mean - pivot|)^2 of a channel instead of with its mean^2 -- a near-constant channel (variance <<
+    // mean^2) would otherwise lose its variance to that rounding.  pivot = the trimmed mean (largest and smallest dropped) of SIXTEEN rows spread evenly over the cloud (every
+    // wave and chunk of the cloud loads the same ones and adds them in the same order: one value per cloud and channel).  Round 5: it
+    // used to be the cloud's FIRST row -- on a real 3DMatch fragment that row can be an outlier (an isolated point whose kernel-point sums
+    // are a tenth of the typical ones), the pivot then sits ~6 sigma from the mean and the statistics lose a factor ~36: 3e-5 on the encoder
+    // output of one cloud in nine (tools/real_diag.py), against 2e-6 from a pivot near the mean.  k_tail_prepare adds the pivot back.
     float pv[KC];
     {
         const int r0 = seg_off[cloud];
-        const float d0 = ROWDIV ? row_div[r0] : 1.f;
+        const long long n_c = c_end - r0;
+        float v16[16][KC], d16[ROWDIV ? 16 : 1];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int row = r0 + (int)(((2 * i + 1) * n_c) >> 5);
+#pragma unroll
+            for (int c = 0; c < KC; c++) v16[i][c] = A[(size_t)row * lda + 32 * c + chc];
+            if (ROWDIV) d16[i] = row_div[row];
+        }
 #pragma unroll
         for (int c = 0; c < KC; c++) {
-            float v = A[(size_t)r0 * lda + 32 * c + chc];
-            if (ROWDIV) v = v / d0;
-            if (INFOLD) { const float u = (v - mu[c]) * rs[c]; v = fmaxf(u, u * slope); }
-            pv[c] = ch_ok ? v : 0.f;
+            float acc16 = 0.f, lo = 3.0e38f, hi = -3.0e38f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float v = v16[i][c];
+                if (ROWDIV) v = v / d16[ROWDIV ? i : 0];
+                if (INFOLD) { const float u = (v - mu[c]) * rs[c]; v = fmaxf(u, u * slope); }
+                acc16 += v; lo = fminf(lo, v); hi = fmaxf(hi, v);
+            }
+            pv[c] = ch_ok ? (acc16 - lo - hi) * (1.f / 14.f) : 0.f;      // trimmed: one sampled outlier does not move it
         }
     }
     // float32 accumulation over the wave's <= 512 rows (rounding ~1e-6 of a sum, independent between the ~40 waves of a cloud),

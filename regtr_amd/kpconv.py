@@ -42,7 +42,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, context, ops
 from .kernel_points import load_kernels
 
 
@@ -420,6 +420,11 @@ class KPFEncoder(nn.Module):
     def forward(self, x, batch, start=0, stop=None, skip_x=None):
         """Blocks [start, stop) (all by default); skip_x carries the skip list across a split call."""
         skip_x = [] if skip_x is None else skip_x
+        stop_i = len(self.encoder_blocks) if stop is None else min(stop, len(self.encoder_blocks))
+        if start < stop_i and self._one_call_ok(x, batch):
+            y = self._forward_one_call(x, batch, start, stop_i)
+            if y is not None:
+                return y, skip_x            # (the skip list feeds a decoder RegTR does not have, kpconv.py:93-94: not collected on this path)
         for block_i, block_op in enumerate(self.encoder_blocks):
             if block_i < start or (stop is not None and block_i >= stop):
                 continue
@@ -427,6 +432,90 @@ class KPFEncoder(nn.Module):
                 skip_x.append(x)
             x = block_op(x, batch)
         return x, skip_x
+
+    # ---- blocks [start, stop) through ONE C call (regtr_encoder_fwd, csrc/encoder.hip): the same launches in the same order, sequenced in C.
+    # Small batches only (a pair or two per forward: the reference's own mode), where the host is the bound of an op-by-op forward.
+    def _one_call_ok(self, x, meta):
+        ctx = context.current()
+        return bool(ops.use_one_call_encoder and ctx.gather_records is None and ctx.gemm_records is None and ctx.f16_range_log is None
+                    and not ops.force_f32_gemm and not ops.force_x3_gemm and ops.use_tile_info and ops.preapply_unary2 == 1
+                    and meta['points'][0].shape[0] < ops.PRENORM_MIN_ROWS and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                    and x.shape[0] > 0)
+
+    def _block_table(self):
+        """ctypes array of regtr_encoder_block_t for the blocks, rebuilt when a parameter (version / storage) changes; the tensors behind
+        the pointers are kept alive by the blocks' weight caches."""
+        key, rows = [], []
+        for blk in self.encoder_blocks:
+            kp = blk.KPConv
+            ws = [None, None, None, None]
+            ws[1] = _prepared(kp._cache, 'w', kp.weights, lambda p, kp=kp: ops.SplitWeight(p.view(kp.K * kp.in_channels, kp.out_channels), 'kn'))
+            kind = 0
+            if isinstance(blk, ResnetBottleneckBlock):
+                kind = 1
+                for i, u in ((0, blk.unary1), (2, blk.unary2), (3, blk.unary_shortcut)):
+                    if isinstance(u, UnaryBlock):
+                        ws[i] = _prepared(u._cache, 'w', u.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
+            rows.append((blk, kind, ws))
+            key += [(id(w), w.kn.data_ptr()) for w in ws if w is not None] + [kp.kernel_points.data_ptr(), kp.kernel_points._version]
+        key = tuple(key)
+        if getattr(self, '_table', None) is None or self._table[0] != key:
+            arr = (_lib.EncoderBlock * len(rows))()
+            keep = []
+            for e, (blk, kind, ws) in zip(arr, rows):
+                kp = blk.KPConv
+                e.kind, e.strided, e.layer = kind, int('strided' in blk.block_name), int(blk.layer_ind)
+                e.n_kp, e.extent = int(kp.K), float(kp.KP_extent)
+                e.kernel_points = _lib.ptr(kp.kernel_points.detach())
+                for name, w in zip(('unary1', 'conv', 'unary2', 'shortcut'), ws):
+                    f = getattr(e, name)
+                    if w is None:
+                        f.kn = f.planes = f.planes16 = None
+                        f.N = f.K = 0
+                        continue
+                    f.kn = _lib.ptr(w.kn)
+                    f.planes = _lib.bptr(w.planes) if w.planes is not None else None
+                    f.planes16 = _lib.bptr(w.planes16) if (w.planes is not None and w.f16_ok) else None
+                    f.N, f.K = int(w.N), int(w.K)
+                    keep.append(w)
+            self._table = (key, arr, keep)
+        return self._table[1]
+
+    def _forward_one_call(self, x, meta, start, stop):
+        L = _lib.lib()
+        n_levels = len(meta['points'])
+        n_clouds = meta['_seg_off'][0].numel() - 1
+        levels = (_lib.EncoderLevel * n_levels)()
+        lim = None
+        for l, e in enumerate(levels):
+            pts, conv, pool = meta['points'][l], meta['_neighbors_i32'][l], (meta['_pools_i32'][l] if '_pools_i32' in meta else None)
+            e.points, e.n = _lib.ptr(pts), int(pts.shape[0])
+            has_conv = conv is not None and conv.shape[0] == pts.shape[0] and pts.shape[0] > 0
+            e.conv_idx = _lib.iptr(conv) if has_conv else None
+            has_pool = pool is not None and l + 1 < n_levels and pool.shape[0] == meta['points'][l + 1].shape[0] and pool.shape[0] > 0
+            e.pool_idx = _lib.iptr(pool) if has_pool else None
+            e.K = int(conv.shape[1]) if has_conv else (int(pool.shape[1]) if has_pool else 1)
+            if has_conv and has_pool and conv.shape[1] != pool.shape[1]:
+                return None
+            e.pool_width = int(meta['_pool_width'][l]) if ('_pool_width' in meta and has_pool) else e.K
+            e.seg_off, e.max_len = _lib.iptr(meta['_seg_off'][l]), int(max(meta['_lens_host'][l]))
+        blocks = self._block_table()
+        nb_blocks = len(self.encoder_blocks)
+        if not L.regtr_encoder_supported(blocks, nb_blocks, levels, n_levels, n_clouds, start, stop):
+            return None
+        ctx = context.current()
+        f16 = 1 if (ctx.f16_pair and not ctx.force_x3) else 0
+        nb = L.regtr_encoder_ws_bytes(blocks, nb_blocks, levels, n_levels, n_clouds, start, stop, f16)
+        if nb == 0:
+            return None
+        last = self.encoder_blocks[stop - 1]
+        lq = last.layer_ind + (1 if 'strided' in last.block_name else 0)
+        out_dim = last.KPConv.out_channels if isinstance(last, SimpleBlock) else last.unary2.out_dim
+        out = torch.empty((meta['points'][lq].shape[0], out_dim), dtype=torch.float32, device=x.device)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        _lib.check(L.regtr_encoder_fwd(blocks, nb_blocks, levels, n_levels, n_clouds, start, stop, _lib.ptr(x), _lib.ptr(out), f16, 0.1, 1e-5,
+                                       _lib.bptr(ws), nb, ctx.status_ptr(), _lib.stream()), 'regtr_encoder_fwd')
+        return out
 
     def level0_blocks(self):
         """Number of leading blocks that work on level 0 only (not strided): they need nothing but level 0's conv table."""
