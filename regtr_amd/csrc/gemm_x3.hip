@@ -1076,6 +1076,75 @@ __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
     g.C[(size_t)row * g.ldc + col] = v;
 }
 
+// The same reduction WITH the InstanceNorm partial sums of the result (round 5): a split-K launch had no statistics epilogue, so a KPConv
+// contraction of a small batch was four launches -- product, this reduction, regtr_instnorm_stats' two -- and the statistics pass re-read
+// the C just written.  Here one workgroup owns X3_RS_ROWS rows x all N columns: thread (tx = column quad, ty = row phase) adds the S
+// partial products of its elements in split order (the same sum as above), applies the epilogue, stores, and keeps per-column (sum, sum of
+// squares) in float64 for every cloud owning rows of the tile; the ty phases are added in fixed order through LDS and the tile's slots
+// written in regtr_gemm_x3's own layout -- stat_partial[(tile + cloud) * N + col] -- so regtr_instnorm_finalize_tiles(tile_rows =
+// X3_RS_ROWS) finishes the job as for every other launch.  N / 4 must be a power of two <= 256 (every RegTR width).
+constexpr int X3_RS_ROWS = 32;
+
+__global__ void __launch_bounds__(256) k_x3_splitk_reduce_stats(X3Args g, int S, int vec_ok)
+{
+    __shared__ double sh[256 * 8];
+    const int C4 = g.N >> 2, TR = 256 / C4;
+    const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
+    const int tile = blockIdx.x, r0 = tile * X3_RS_ROWS, r1 = min(g.M, r0 + X3_RS_ROWS);
+    const int s_lo = rg_find_segment(g.stat_seg_off, g.n_stat_seg, r0), s_hi = rg_find_segment(g.stat_seg_off, g.n_stat_seg, r1 - 1);
+    const int col = 4 * tx;
+    const size_t plane = (size_t)g.M * g.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.bias) bv = *(const float4*)(g.bias + col);
+    for (int sg = s_lo; sg <= s_hi; sg++) {                              // workgroup-uniform; one cloud per tile almost always
+        const int lo = max(r0, g.stat_seg_off[sg]), hi = min(r1, g.stat_seg_off[sg + 1]);
+        if (lo >= hi) continue;                                           // an empty cloud between two others
+        double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+        for (int r = lo + ty; r < hi; r += TR) {
+            const float* P = g.partial + (size_t)r * g.N + col;
+            float4 a = *(const float4*)P;
+            for (int k = 1; k < S; k++) {                                 // fixed order: deterministic
+                const float4 b = *(const float4*)(P + (size_t)k * plane);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            float v[4] = {a.x, a.y, a.z, a.w};
+            if (g.row_div) { const float d = g.row_div[r];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = v[j] / d; }
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            if (g.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (g.residual) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] += g.residual[(size_t)r * g.ldr + col + j];
+            }
+            if (vec_ok) *(float4*)(g.C + (size_t)r * g.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) g.C[(size_t)r * g.ldc + col + j] = v[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { sm[j] += (double)v[j]; sq[j] += (double)v[j] * (double)v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { sh[threadIdx.x * 8 + j] = sm[j]; sh[threadIdx.x * 8 + 4 + j] = sq[j]; }
+        __syncthreads();
+        if (ty == 0) {
+            for (int y = 1; y < TR; y++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) { sm[j] += sh[(y * C4 + tx) * 8 + j]; sq[j] += sh[(y * C4 + tx) * 8 + 4 + j]; }
+            double2* o = g.stat_partial + (size_t)(tile + sg) * g.N + col;
+#pragma unroll
+            for (int j = 0; j < 4; j++) o[j] = make_double2(sm[j], sq[j]);
+        }
+        __syncthreads();
+    }
+}
+
+static inline bool x3_rs_ok(int N) { const int c4 = N >> 2; return N % 4 == 0 && c4 >= 1 && c4 <= 256 && (c4 & (c4 - 1)) == 0; }
+
 // W (rows x cols, leading dimension ld) -> Wt[p][n][k]: n = row (transposed == 0: W is [N, K], an nn.Linear weight) or
 // n = col (transposed == 1: W is [K, N]).  Padding (k >= K, n >= N) is zero.
 __global__ void __launch_bounds__(256) k_split_weights(const float* __restrict__ W, int ld, int N, int K, int transposed,
@@ -1278,13 +1347,14 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K)
 }
 
 // Same contract as regtr_gemm_f32 with B given as the planes written by regtr_gemm_split_weights(W, .., N, K, ..).
-// rows per statistics tile when regtr_gemm_x3 can emit InstanceNorm partial sums for this shape in its epilogue
-// (stat_partial), 0 when it cannot (split-K shapes): the caller then runs regtr_instnorm_stats on C instead.
+// rows per statistics tile when regtr_gemm_x3 can emit InstanceNorm partial sums for this shape (stat_partial): the launch's tile height
+// when they come from the GEMM epilogue, X3_RS_ROWS when a split-K launch's reduction kernel writes them; 0 when it cannot (split-K with a
+// column count the reduction's thread map does not take): the caller then runs regtr_instnorm_stats on C instead.
 int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
 {
     if (!regtr_gemm_x3_supported(M, N, K) || M < 1) return 0;
     const X3Plan p = x3_plan(M, N, K);
-    if (p.splits > 1) return 0;
+    if (p.splits > 1) return x3_rs_ok(N) ? X3_RS_ROWS : 0;
     return p.tile == 2 ? 64 : 128;
 }
 
@@ -1318,7 +1388,10 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     //  same 128-row statistics slots)
     if (n_planes == 4 && p.tile == 0 && (!p.strip || a_stats || K % XBK || p.k_chunk % XBK)) p.tile = 1;
     if (p.splits > 1 && (!ws || ws_bytes < (size_t)p.splits * M * N * sizeof(float))) return RG_ERR_WORKSPACE;
-    if (stat_partial && (p.splits > 1 || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
+    if (stat_partial && ((p.splits > 1 && !x3_rs_ok(N)) || !stat_seg_off || n_stat_seg < 1 || ((uintptr_t)stat_partial % 16))) return RG_ERR_ARG;
+    // split-K: the product kernel writes raw partial products; the statistics (if asked for) come from the reduction kernel
+    double* const stat_all = stat_partial;
+    if (p.splits > 1) stat_partial = nullptr;
     const int Npad = rg_cdiv(N, 128) * 128, Kp = rg_cdiv(K, XBK) * XBK;
     X3Args g{A, (const uint16_t*)planes, C, bias, row_div, residual, (const float2*)a_stats, a_seg_off,
              p.splits > 1 ? (float*)ws : nullptr, (double2*)stat_partial, stat_seg_off, (const int4*)tile_info, (size_t)Npad * Kp,
@@ -1365,7 +1438,14 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     else X3_LAUNCH(2, 2, 1, 1);                      // 64 x 64, 4 waves of 32 x 32
 #undef X3_LAUNCH
 #undef X3D_LAUNCH
-    if (p.splits > 1) k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
+    if (p.splits > 1 && stat_all) {
+        X3Args gr = g;
+        gr.stat_partial = (double2*)stat_all;
+        const int vec_ok = (ldc % 4 == 0 && (uintptr_t)C % 16 == 0) ? 1 : 0;
+        k_x3_splitk_reduce_stats<<<rg_cdiv(M, X3_RS_ROWS), 256, 0, st>>>(gr, p.splits, vec_ok);
+    } else if (p.splits > 1) {
+        k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
+    }
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

@@ -9,7 +9,20 @@
 
 namespace {
 
-constexpr int IN_ROWS = 128;   // rows of one cloud handled by one workgroup
+constexpr int IN_ROWS = 128;   // rows of one cloud handled by one workgroup (large launches)
+
+// Rows per workgroup of a launch over clouds of at most max_len rows.  128 everywhere a launch fills the chip anyway; a pair or two per forward
+// leaves the deep levels with a handful of 128-row workgroups (751 rows x 1024 channels: 8 workgroups, each thread walking 128 rows -- 35 us
+// for 9 MB), so the chunk is halved until the launch has ~1000 workgroups or a workgroup is down to four row steps / 8 rows.  Host-side
+// and a function of the launch geometry only (never of the data); the statistics kernels add a cloud's chunks in chunk order whatever their
+// length, so results stay run-to-run deterministic.
+inline int in_rows(int max_len, int n_clouds, int C)
+{
+    const int TR = 256 / (C >> 2);
+    int rows = IN_ROWS;
+    while (rows > 4 * TR && rows > 8 && (long long)rg_cdiv(max_len > 0 ? max_len : 1, rows) * n_clouds < 1024) rows >>= 1;
+    return rows;
+}
 
 // Thread mapping shared by the InstanceNorm kernels: C4 = C/4 float4 columns (a power of two <= 256); thread
 // (tx = t % C4, ty = t / C4) owns column group tx for rows ty, ty + TR, ... so that every row is one contiguous read and
@@ -17,11 +30,11 @@ constexpr int IN_ROWS = 128;   // rows of one cloud handled by one workgroup
 
 // partial[(cloud * nchunk + chunk) * C + c] = (sum, sumsq) over the chunk's rows, accumulated in float64
 __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
-                                                          int nchunk, double2* __restrict__ partial)
+                                                          int nchunk, int rows, double2* __restrict__ partial)
 {
     __shared__ double sh[256 * 8];
     const int b = blockIdx.y, chunk = blockIdx.x;
-    const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
+    const int r0 = seg_off[b] + chunk * rows, r1 = min(seg_off[b + 1], r0 + rows);
     if (r0 >= r1) return;
     const int C4 = C >> 2, TR = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
@@ -57,13 +70,13 @@ __global__ void __launch_bounds__(256) k_instnorm_partial(const float* __restric
 
 // stats[(cloud * C + c)] = (mean, 1/sqrt(var + eps)); one wave per (cloud, channel) sums the chunks in a fixed tree
 __global__ void __launch_bounds__(256) k_instnorm_finalize(const double2* __restrict__ partial, const int* __restrict__ seg_off,
-                                                           int C, int nchunk, float eps, float2* __restrict__ stats)
+                                                           int C, int nchunk, int rows, float eps, float2* __restrict__ stats)
 {
     const int b = blockIdx.y, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (c >= C) return;
     const int lane = rg_lane();
     const int n = seg_off[b + 1] - seg_off[b];
-    const int used = (n + IN_ROWS - 1) / IN_ROWS;
+    const int used = (n + rows - 1) / rows;
     double s = 0, ss = 0;
     for (int k = lane; k < used; k += RG_WAVE) {
         const double2 p = partial[((size_t)b * nchunk + k) * C + c];
@@ -149,10 +162,10 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
                                                         const float2* __restrict__ stats, const float* __restrict__ res,
                                                         const float2* __restrict__ res_stats, int act, float slope,
                                                         float* __restrict__ y, const float* __restrict__ row_xyz,
-                                                        float* __restrict__ row_positive)
+                                                        float* __restrict__ row_positive, int rows)
 {
     const int b = blockIdx.y, chunk = blockIdx.x;
-    const int r0 = seg_off[b] + chunk * IN_ROWS, r1 = min(seg_off[b + 1], r0 + IN_ROWS);
+    const int r0 = seg_off[b] + chunk * rows, r1 = min(seg_off[b + 1], r0 + rows);
     if (r0 >= r1) return;
     const int C4 = C >> 2, TR = 256 / C4;
     const int tx = threadIdx.x % C4, ty = threadIdx.x / C4;
@@ -266,7 +279,8 @@ extern "C" {
 
 size_t regtr_instnorm_ws_bytes(int n_clouds, int max_len, int C)
 {
-    const size_t nchunk = (size_t)rg_cdiv(max_len > 0 ? max_len : 1, IN_ROWS);
+    if (n_clouds < 1 || C < 4 || C % 4 || C > 1024 || 256 % (C / 4)) return 256;
+    const size_t nchunk = (size_t)rg_cdiv(max_len > 0 ? max_len : 1, in_rows(max_len, n_clouds, C));
     return nchunk * n_clouds * C * sizeof(double2) + 256;
 }
 
@@ -279,9 +293,10 @@ int regtr_instnorm_stats(const float* x, const int* seg_off, int n_clouds, int m
     if (ws_bytes < regtr_instnorm_ws_bytes(n_clouds, max_len, C)) return RG_ERR_WORKSPACE;
     if (max_len == 0) return RG_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nchunk = rg_cdiv(max_len, IN_ROWS);
-    k_instnorm_partial<<<dim3(nchunk, n_clouds), 256, 0, st>>>(x, seg_off, C, nchunk, (double2*)ws);
-    k_instnorm_finalize<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, eps,
+    const int rows = in_rows(max_len, n_clouds, C);
+    const int nchunk = rg_cdiv(max_len, rows);
+    k_instnorm_partial<<<dim3(nchunk, n_clouds), 256, 0, st>>>(x, seg_off, C, nchunk, rows, (double2*)ws);
+    k_instnorm_finalize<<<dim3(rg_cdiv(C, 4), n_clouds), 256, 0, st>>>((const double2*)ws, seg_off, C, nchunk, rows, eps,
                                                                          (float2*)stats);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
@@ -316,8 +331,9 @@ int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int m
     if (C > 1024 || 256 % (C / 4) || (row_positive && C > 256) || (row_xyz && (!row_positive || (uintptr_t)row_positive % 16)))
         return RG_ERR_ARG;
     if (max_len == 0) return RG_OK;
-    k_instnorm_apply<<<dim3(rg_cdiv(max_len, IN_ROWS), n_clouds), 256, 0, (hipStream_t)stream>>>(
-        x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y, row_xyz, row_positive);
+    const int rows = in_rows(max_len, n_clouds, C);
+    k_instnorm_apply<<<dim3(rg_cdiv(max_len, rows), n_clouds), 256, 0, (hipStream_t)stream>>>(
+        x, seg_off, C, (const float2*)stats, residual, (const float2*)res_stats, act, slope, y, row_xyz, row_positive, rows);
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;
 }

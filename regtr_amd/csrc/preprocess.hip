@@ -105,9 +105,80 @@ __global__ void __launch_bounds__(SCAN_THREADS) k_scan_apply(const uint64_t* __r
     }
 }
 
+// The same scan in ONE launch for small inputs (at most SCAN_CHAIN_TILES tiles = 65536 items: a pair or two per forward, where the
+// pyramid is ~80 launches of 2-30 us paced by the host and every launch removed is ~3 us of host and ~4 us of GPU time): chained scan
+// with decoupled look-back.  state[0] = ticket counter, state[1 + t] = descriptor of tile t: 2 flag bits (0 not ready, 1 = the tile's own
+// sum, 2 = its inclusive prefix) over a 62-bit value; the caller's clear kernel (k_clear_tables, earlier in the stream) zeroes
+// state[0 .. nb].  Tile ids come from the ticket, so every predecessor of a running tile has started: no deadlock whatever the dispatch
+// order.  Wave 0 reads ALL predecessors of its tile at once (<= 63: one memory round trip per attempt), takes the nearest published
+// prefix and adds the sums in front of it.  Integer addition: the result is the three-launch scan's, bit for bit.
+constexpr int SCAN_CHAIN_TILES = 64;
+constexpr uint64_t SC_SUM = 1ull << 62, SC_PREFIX = 2ull << 62, SC_VALUE = (1ull << 62) - 1;
+
+__global__ void __launch_bounds__(SCAN_THREADS) k_scan_chained(const uint64_t* __restrict__ in, const int* __restrict__ n_ptr,
+                                                              uint64_t* __restrict__ state, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t sh[SCAN_THREADS / RG_WAVE + 1];
+    __shared__ int s_tile;
+    __shared__ uint64_t s_prefix;
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd((unsigned*)state, 1u);
+    __syncthreads();
+    const int tile = s_tile, n = *n_ptr;
+    const int base = tile * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint64_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = base + k < n ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint64_t tot;
+    uint64_t ex = block_exclusive_scan(s, &tot, sh);
+    if (threadIdx.x < RG_WAVE) {                                      // wave 0: publish, look back
+        const int lane = threadIdx.x;
+        uint64_t* desc = state + 1;
+        if (tile == 0) {
+            if (lane == 0) {
+                __hip_atomic_store(&desc[0], SC_PREFIX | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = 0;
+            }
+        } else {
+            if (lane == 0) __hip_atomic_store(&desc[tile], SC_SUM | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            // lane l looks at tile - 1 - l; lanes beyond tile 0 stand for "the prefix in front of tile 0" = a published 0
+            uint64_t d;
+            int fp;
+            for (;;) {
+                d = lane < tile ? __hip_atomic_load(&desc[tile - 1 - lane], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : SC_PREFIX;
+                const unsigned long long is_p = __ballot((d >> 62) == 2), not_ready = __ballot((d >> 62) == 0);
+                fp = __ffsll((long long)is_p) - 1;                      // nearest predecessor holding an inclusive prefix (always >= 0)
+                if ((not_ready & ((2ull << fp) - 1ull)) == 0) break;    // everything between it and this tile has published its sum
+                __builtin_amdgcn_s_sleep(1);
+            }
+            uint64_t run = lane <= fp ? (d & SC_VALUE) : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) run += __shfl_xor(run, o, RG_WAVE);
+            if (lane == 0) {
+                __hip_atomic_store(&desc[tile], SC_PREFIX | (run + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = run;
+            }
+        }
+    }
+    __syncthreads();
+    ex += s_prefix;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+}
+
+// bsum: rg_cdiv(n_cap, SCAN_TILE) + 1 entries; when that is at most SCAN_CHAIN_TILES + 1 the caller's clear kernel must have zeroed them
 int scan_u64(const uint64_t* in, const int* n_ptr, int n_cap, uint64_t* bsum, uint64_t* out, hipStream_t st)
 {
     const int nb = rg_cdiv(n_cap, SCAN_TILE);
+    if (nb <= SCAN_CHAIN_TILES) {
+        k_scan_chained<<<nb, SCAN_THREADS, 0, st>>>(in, n_ptr, bsum, out);
+        return RG_OK;
+    }
     k_scan_reduce<<<nb, SCAN_THREADS, 0, st>>>(in, n_ptr, bsum);
     k_scan_bsums<<<1, SCAN_THREADS, 0, st>>>(bsum, nb);
     k_scan_apply<<<nb, SCAN_THREADS, 0, st>>>(in, n_ptr, bsum, out);
@@ -133,11 +204,15 @@ static inline unsigned rg_table_capacity(int n_cap)       // host twin: upper bo
     return rg_next_pow2(want);
 }
 
+// (+ the small-scan state of the call's scan_u64 and, for the grid subsample, the per-cloud boxes: one launch instead of three)
 __global__ void __launch_bounds__(256) k_clear_tables(const int* __restrict__ n_ptr, int* __restrict__ rep, int* __restrict__ cnt,
-                                                      int* __restrict__ fill, int* __restrict__ first)
+                                                      int* __restrict__ fill, int* __restrict__ first, uint64_t* __restrict__ scan_state,
+                                                      int n_state, int* __restrict__ bbox, int n_bbox)
 {
     const unsigned T = rg_live_table(*n_ptr);
     const unsigned h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h < (unsigned)n_state) scan_state[h] = 0;
+    if (h < (unsigned)n_bbox) bbox[h] = (h % 6) < 3 ? INT_MAX : INT_MIN;
     if (h >= T) return;
     rep[h] = -1; cnt[h] = 0; fill[h] = 0;
     if (first) first[h] = 0x7F7F7F7F;
@@ -162,12 +237,6 @@ __device__ __forceinline__ int hash_insert(int* __restrict__ rep, unsigned mask,
 // ------------------------------------------------------------------------------------------------
 // grid subsample
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init_bbox(int* __restrict__ bbox, int n_clouds)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_clouds * 6) bbox[i] = (i % 6) < 3 ? INT_MAX : INT_MIN;
-}
-
 // per-cloud min / max corner  (cloud.cpp:27-66).  Each wave walks BBOX_ITEMS strided points per lane and keeps a running
 // box in registers while the cloud stays the same, so the global atomics are ~one set per wave per cloud.
 constexpr int BBOX_ITEMS = 8;
@@ -192,13 +261,13 @@ __device__ __forceinline__ void bbox_flush(int cid, float (&mn)[3], float (&mx)[
 }
 
 __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, const int* __restrict__ seg_off, int n_clouds,
-                                              int* __restrict__ pcid, int* __restrict__ bbox)
+                                              int* __restrict__ pcid, int* __restrict__ bbox, int items)
 {
     const int n = seg_off[n_clouds];
-    const int base = blockIdx.x * (256 * BBOX_ITEMS) + threadIdx.x;
+    const int base = blockIdx.x * (256 * items) + threadIdx.x;
     int cur = -1;   // cloud of the running box (wave-uniform)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int j = 0; j < BBOX_ITEMS; j++) {
+    for (int j = 0; j < items; j++) {
         const int i = base + j * 256;
         const bool live = i < n;
         int cid = -1;
@@ -827,7 +896,7 @@ GridBuffers carve_grid(void* ws, size_t ws_bytes, int ns_cap)
     b.rep = c.take<int>(T); b.cnt = c.take<int>(T); b.fill = c.take<int>(T);
     b.tkey = c.take<uint64_t>(T); b.tcid = c.take<int>(T);
     b.scan_in = c.take<uint64_t>(T); b.cell_start = c.take<uint64_t>(T);
-    b.bsum = c.take<uint64_t>(rg_cdiv(T, SCAN_TILE) + 1);
+    b.bsum = c.take<uint64_t>(rg_cdiv(T, SCAN_TILE) + 2);           // scan state (ticket + one descriptor per tile) + the live table length
     b.sorted = c.take<float4>(ns_cap);
     b.slots = c.take<CellSlot>(T);
     b.bytes = rg_align_up(c.off, 256);
@@ -897,9 +966,14 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
     const int* n_ptr = seg_off + n_clouds;
     const int nb = rg_cdiv(n_cap, 256);
 
-    k_clear_tables<<<rg_cdiv(T, 256), 256, 0, st>>>(n_ptr, rep, cnt, fill, first);
-    k_init_bbox<<<rg_cdiv(n_clouds * 6, 256), 256, 0, st>>>(bbox, n_clouds);
-    k_bbox<<<rg_cdiv(n_cap, 256 * BBOX_ITEMS), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
+    const int n_state = rg_cdiv(n_cap, SCAN_TILE) + 1;
+    const int n_clear = (int)T > n_clouds * 6 ? (int)T : n_clouds * 6;       // (n_state <= T always: T >= 1.5 n_cap)
+    k_clear_tables<<<rg_cdiv(n_clear, 256), 256, 0, st>>>(n_ptr, rep, cnt, fill, first, n_state <= SCAN_CHAIN_TILES + 1 ? bsum : nullptr,
+                                                          n_state <= SCAN_CHAIN_TILES + 1 ? n_state : 0, bbox, n_clouds * 6);
+    // points per lane of the box pass: 8 keeps the global atomics at ~one set per wave and cloud on large inputs; a pair or two per
+    // forward would be 18 workgroups walking 8 dependent loads each (15-19 us) -- fewer items, more workgroups there
+    const int items = n_cap >= 256 * 256 * BBOX_ITEMS ? BBOX_ITEMS : (n_cap >= 256 * 256 * 2 ? 2 : 1);
+    k_bbox<<<rg_cdiv(n_cap, 256 * items), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, items);
     k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, key_mode, pkey);
     k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, slot_of, first, cnt);
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);
@@ -940,14 +1014,16 @@ int regtr_cellgrid_build(const float* s_xyz, const int* s_seg_off, int n_clouds,
     GridBuffers b = carve_grid(ws, ws_bytes, cap);
     const int* n_ptr = s_seg_off + n_clouds;
     const double inv_cs = 1.0 / ((double)radius * (1.0 + 1e-6));
-    k_clear_tables<<<rg_cdiv(b.T, 256), 256, 0, st>>>(n_ptr, b.rep, b.cnt, b.fill, nullptr);
+    const int n_state = rg_cdiv(b.T, SCAN_TILE) + 1;
+    k_clear_tables<<<rg_cdiv(b.T, 256), 256, 0, st>>>(n_ptr, b.rep, b.cnt, b.fill, nullptr, n_state <= SCAN_CHAIN_TILES + 1 ? b.bsum : nullptr,
+                                                      n_state <= SCAN_CHAIN_TILES + 1 ? n_state : 0, nullptr, 0);
     if (ns_cap > 0) {
         const int nb = rg_cdiv(ns_cap, 256);
         k_cell_keys<<<nb, 256, 0, st>>>(s_xyz, s_seg_off, n_clouds, inv_cs, b.pkey, b.pcid);
         k_insert<<<nb, 256, 0, st>>>(n_ptr, b.pkey, b.pcid, b.rep, b.slot_of, nullptr, b.cnt);
     }
     // the live table length is computed on the device and kept in bsum's tail for the device-n scan
-    int* tn = (int*)(b.bsum + rg_cdiv(b.T, SCAN_TILE));
+    int* tn = (int*)(b.bsum + rg_cdiv(b.T, SCAN_TILE) + 1);
     k_table_keys<<<rg_cdiv(b.T, 256), 256, 0, st>>>(b.rep, n_ptr, b.pkey, b.pcid, b.cnt, b.tkey, b.tcid, b.scan_in, tn);
     scan_u64(b.scan_in, tn, (int)b.T, b.bsum, b.cell_start, st);
     if (ns_cap > 0)

@@ -84,10 +84,13 @@ class Preprocessor(nn.Module):
             meta = self.finish(self.enqueue(pts))
         return meta
 
-    def enqueue(self, pts: List[torch.Tensor], level0_event=None):
+    def enqueue(self, pts: List[torch.Tensor], level0_event=None, after_level0=None):
         """Enqueues the whole pyramid on the current stream without touching the host (default order only; the parity mode's KD-tree
         reads its row widths back).  level0_event: recorded as soon as level 0's conv table is complete -- everything the level-0
         blocks need (RegTR.forward starts them on its main stream while the rest of the pyramid is still being built on this one).
+        after_level0(meta0): called right after that event, BEFORE the rest of the pyramid is enqueued -- small batches, where the
+        pyramid's ~80 launches are paced by the host: the level-0 blocks must be in the main stream's queue before the host spends
+        another 0.4 ms enqueuing levels 1-3, or there is nothing for them to overlap with.
         -> state for finish() / level0_meta()."""
         cfg = self.cfg
         limits = cfg.neighborhood_limits
@@ -147,6 +150,8 @@ class Preprocessor(nn.Module):
                     conv_i = grid.query(points, seg, cap, K, order=nb_order)             # :349-351
                 if layer == 0 and level0_event is not None:
                     level0_event.record()
+                    if after_level0 is not None:
+                        after_level0({'points': [points], '_neighbors_i32': [conv_i], '_seg_off': [seg], '_lens_host': [lens0]})
                 if strided:
                     pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, key_mode=key_mode, out_cap=cap_next)          # :366 / :213-240
                     pool_i = grid.query(pool_p, pool_seg, cap_next, K, order=nb_order)   # :376

@@ -41,6 +41,7 @@ class PositionEmbeddingCoordsSine(nn.Module):
 # A-B switch and size gate of the two-stream forward (RegTR._forward)
 overlap_preprocessing = devflags.on('REGTR_OVERLAP')          # (read only under REGTR_DEV=1)
 OVERLAP_MIN_POINTS = 131072
+SMALL_OVERLAP = devflags.on('REGTR_SMALL_OVERLAP')      # the level-0 blocks of a small batch under the host's enqueue of pyramid levels 1-3
 
 
 class CorrespondenceRegressor(nn.Module):
@@ -253,8 +254,8 @@ class RegTR(nn.Module):
         clouds = batch['src_xyz'] + batch['tgt_xyz']
         n0 = sum(int(p.shape[0]) for p in clouds)
         n_l0 = self.kpf_encoder.level0_blocks()
-        if (overlap_preprocessing and n0 >= OVERLAP_MIN_POINTS and n_l0 > 0 and not ev
-                and not self.cfg.get('kpconv_ref_row_order', False)):
+        two_streams = (overlap_preprocessing and n_l0 > 0 and not ev and not self.cfg.get('kpconv_ref_row_order', False))
+        if two_streams and n0 >= OVERLAP_MIN_POINTS:
             # Large batches: the pyramid is built on a second HIP stream, and the level-0 blocks -- which need only level 0's conv
             # table and sizes the host already knows -- start on the main stream as soon as that table exists: the other 2.4 ms of
             # pyramid building (latency-bound small kernels) run under 6 ms of bandwidth-bound level-0 convolution.
@@ -277,6 +278,30 @@ class RegTR(nn.Module):
                 self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
+        elif two_streams and SMALL_OVERLAP and n0 < ops.PRENORM_MIN_ROWS and ops.use_one_call_encoder:
+            # A pair or two per forward (the reference's own mode): the pyramid's ~80 launches of 2-30 us are paced by the HOST (~0.55 ms to
+            # enqueue), and the encoder cannot start before the level sizes have been read back.  The level-0 blocks need neither: their
+            # sizes are the inputs' own.  So they are handed to the main stream (ONE C call, regtr_encoder_fwd) the moment level 0's conv
+            # table is enqueued, and run (0.25 ms of GPU time) while the host is still enqueuing levels 1-3 on the side stream.
+            main = torch.cuda.current_stream()
+            side = self._side_stream(dev)
+            ev0 = torch.cuda.Event()
+            side.wait_stream(main)
+            carried = {}
+
+            def level0_blocks(meta0):
+                for t in (meta0['points'][0], meta0['_neighbors_i32'][0], meta0['_seg_off'][0]):
+                    t.record_stream(main)
+                with torch.cuda.stream(main):
+                    main.wait_event(ev0)
+                    feats0 = torch.ones_like(meta0['points'][0][:, 0:1])
+                    carried['x'], carried['skips'] = self.kpf_encoder(feats0, meta0, 0, n_l0)
+            with torch.cuda.stream(side):
+                state = self.preprocessor.enqueue(clouds, level0_event=ev0, after_level0=level0_blocks)
+            kpconv_meta = self.preprocessor.finish(state)
+            self._record_meta(kpconv_meta, main)                     # (small batches are sized at full capacity: finish() cannot ask for a rebuild)
+            batch['kpconv_meta'] = kpconv_meta
+            feats_un, _ = self.kpf_encoder(carried['x'], kpconv_meta, n_l0, None, carried['skips'])
         else:
             kpconv_meta = self.preprocessor(clouds)
             batch['kpconv_meta'] = kpconv_meta
