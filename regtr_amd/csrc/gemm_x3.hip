@@ -1082,10 +1082,13 @@ __global__ void __launch_bounds__(256) k_x3_splitk_reduce(X3Args g, int S)
 // partial products of its elements in split order (the same sum as above), applies the epilogue, stores, and keeps per-column (sum, sum of
 // squares) in float64 for every cloud owning rows of the tile; the ty phases are added in fixed order through LDS and the tile's slots
 // written in regtr_gemm_x3's own layout -- stat_partial[(tile + cloud) * N + col] -- so regtr_instnorm_finalize_tiles(tile_rows =
-// X3_RS_ROWS) finishes the job as for every other launch.  N / 4 must be a power of two <= 256 (every RegTR width).
-constexpr int X3_RS_ROWS = 32;
+// x3_rs_rows(N)) finishes the job as for every other launch.  N / 4 must be a power of two <= 256 (every RegTR width).
+// Tile height = ONE row per thread row-phase (1024 / N rows: 4 at N = 256): split-K launches are small problems by construction (fewer than
+// 384 tiles), and a first version with 32-row tiles left a 751-row level with 24 workgroups walking eight rows each -- 11.9 us against 4.8 +
+// 4.7 us for the two kernels it replaced.
+static inline int x3_rs_rows(int N) { return N >= 1024 ? 1 : 1024 / N; }
 
-__global__ void __launch_bounds__(256) k_x3_splitk_reduce_stats(X3Args g, int S, int vec_ok)
+__global__ void __launch_bounds__(256) k_x3_splitk_reduce_stats(X3Args g, int S, int vec_ok, int X3_RS_ROWS)
 {
     __shared__ double sh[256 * 8];
     const int C4 = g.N >> 2, TR = 256 / C4;
@@ -1348,13 +1351,13 @@ size_t regtr_gemm_x3_ws_bytes(int M, int N, int K)
 
 // Same contract as regtr_gemm_f32 with B given as the planes written by regtr_gemm_split_weights(W, .., N, K, ..).
 // rows per statistics tile when regtr_gemm_x3 can emit InstanceNorm partial sums for this shape (stat_partial): the launch's tile height
-// when they come from the GEMM epilogue, X3_RS_ROWS when a split-K launch's reduction kernel writes them; 0 when it cannot (split-K with a
+// when they come from the GEMM epilogue, 1024 / N when a split-K launch's reduction kernel writes them; 0 when it cannot (split-K with a
 // column count the reduction's thread map does not take): the caller then runs regtr_instnorm_stats on C instead.
 int regtr_gemm_x3_stat_tile_rows(int M, int N, int K)
 {
     if (!regtr_gemm_x3_supported(M, N, K) || M < 1) return 0;
     const X3Plan p = x3_plan(M, N, K);
-    if (p.splits > 1) return x3_rs_ok(N) ? X3_RS_ROWS : 0;
+    if (p.splits > 1) return x3_rs_ok(N) ? x3_rs_rows(N) : 0;
     return p.tile == 2 ? 64 : 128;
 }
 
@@ -1442,7 +1445,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
         X3Args gr = g;
         gr.stat_partial = (double2*)stat_all;
         const int vec_ok = (ldc % 4 == 0 && (uintptr_t)C % 16 == 0) ? 1 : 0;
-        k_x3_splitk_reduce_stats<<<rg_cdiv(M, X3_RS_ROWS), 256, 0, st>>>(gr, p.splits, vec_ok);
+        k_x3_splitk_reduce_stats<<<rg_cdiv(M, x3_rs_rows(N)), 256, 0, st>>>(gr, p.splits, vec_ok, x3_rs_rows(N));
     } else if (p.splits > 1) {
         k_x3_splitk_reduce<<<rg_cdiv((long long)M * N, 256), 256, 0, st>>>(g, p.splits);
     }

@@ -261,22 +261,32 @@ __device__ __forceinline__ void bbox_flush(int cid, float (&mn)[3], float (&mx)[
 }
 
 __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, const int* __restrict__ seg_off, int n_clouds,
-                                              int* __restrict__ pcid, int* __restrict__ bbox, int items)
+                                              int* __restrict__ pcid, int* __restrict__ bbox)
 {
     const int n = seg_off[n_clouds];
-    const int base = blockIdx.x * (256 * items) + threadIdx.x;
+    const int base = blockIdx.x * (256 * BBOX_ITEMS) + threadIdx.x;
     int cur = -1;   // cloud of the running box (wave-uniform)
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int j = 0; j < items; j++) {
+    // every point of the lane requested up front, from CLAMPED rows (round 5): under the `live` predicate each of the eight iterations
+    // was load -> wait -> use, eight dependent memory round trips per lane -- 15-19 us on a 40 k-point level whose 18 workgroups
+    // have nothing else to hide them behind (measured and NOT the fix: one point per lane in 8x the workgroups, 27 us -- the box
+    // atomics, one set per wave, serialise at ~90 ns each)
+    float pv[BBOX_ITEMS][3];
+    int cids[BBOX_ITEMS];
+#pragma unroll
+    for (int j = 0; j < BBOX_ITEMS; j++) {
+        const int ic = min(base + j * 256, n > 0 ? n - 1 : 0);
+        pv[j][0] = xyz[3 * (size_t)ic]; pv[j][1] = xyz[3 * (size_t)ic + 1]; pv[j][2] = xyz[3 * (size_t)ic + 2];
+    }
+#pragma unroll
+    for (int j = 0; j < BBOX_ITEMS; j++) cids[j] = base + j * 256 < n ? rg_find_segment(seg_off, n_clouds, base + j * 256) : -1;
+#pragma unroll
+    for (int j = 0; j < BBOX_ITEMS; j++) {
         const int i = base + j * 256;
         const bool live = i < n;
-        int cid = -1;
-        float p[3] = {0.f, 0.f, 0.f};
-        if (live) {
-            cid = rg_find_segment(seg_off, n_clouds, i);
-            pcid[i] = cid;
-            p[0] = xyz[3 * (size_t)i]; p[1] = xyz[3 * (size_t)i + 1]; p[2] = xyz[3 * (size_t)i + 2];
-        }
+        const int cid = cids[j];
+        const float p[3] = {pv[j][0], pv[j][1], pv[j][2]};
+        if (live) pcid[i] = cid;
         const int cid0 = __shfl(cid, 0, RG_WAVE);
         const bool uniform = __all(cid == cid0) && cid0 >= 0;
         if (uniform) {
@@ -970,10 +980,7 @@ int regtr_grid_subsample_ordered(const float* xyz, const int* seg_off, int n_clo
     const int n_clear = (int)T > n_clouds * 6 ? (int)T : n_clouds * 6;       // (n_state <= T always: T >= 1.5 n_cap)
     k_clear_tables<<<rg_cdiv(n_clear, 256), 256, 0, st>>>(n_ptr, rep, cnt, fill, first, n_state <= SCAN_CHAIN_TILES + 1 ? bsum : nullptr,
                                                           n_state <= SCAN_CHAIN_TILES + 1 ? n_state : 0, bbox, n_clouds * 6);
-    // points per lane of the box pass: 8 keeps the global atomics at ~one set per wave and cloud on large inputs; a pair or two per
-    // forward would be 18 workgroups walking 8 dependent loads each (15-19 us) -- fewer items, more workgroups there
-    const int items = n_cap >= 256 * 256 * BBOX_ITEMS ? BBOX_ITEMS : (n_cap >= 256 * 256 * 2 ? 2 : 1);
-    k_bbox<<<rg_cdiv(n_cap, 256 * items), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, items);
+    k_bbox<<<rg_cdiv(n_cap, 256 * BBOX_ITEMS), 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox);
     k_voxel_keys<<<nb, 256, 0, st>>>(xyz, seg_off, n_clouds, pcid, bbox, dl, key_mode, pkey);
     k_insert<<<nb, 256, 0, st>>>(n_ptr, pkey, pcid, rep, slot_of, first, cnt);
     k_leader_flags<<<nb, 256, 0, st>>>(n_ptr, slot_of, first, cnt, scan_in);

@@ -278,11 +278,14 @@ class RegTR(nn.Module):
                 self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
-        elif two_streams and SMALL_OVERLAP and n0 < ops.PRENORM_MIN_ROWS and ops.use_one_call_encoder:
-            # A pair or two per forward (the reference's own mode): the pyramid's ~80 launches of 2-30 us are paced by the HOST (~0.55 ms to
-            # enqueue), and the encoder cannot start before the level sizes have been read back.  The level-0 blocks need neither: their
-            # sizes are the inputs' own.  So they are handed to the main stream (ONE C call, regtr_encoder_fwd) the moment level 0's conv
-            # table is enqueued, and run (0.25 ms of GPU time) while the host is still enqueuing levels 1-3 on the side stream.
+        elif (two_streams and SMALL_OVERLAP and n0 < ops.PRENORM_MIN_ROWS and ops.use_one_call_encoder and self.preprocessor.one_call_ok(n0)
+              and context.current().gather_records is None and context.current().gemm_records is None):
+            # A pair or two per forward (the reference's own mode): the encoder cannot start before the level sizes have been read back
+            # behind the pyramid (~70 launches of 2-30 us, 0.45 ms of GPU time).  The level-0 blocks need no read-back: their sizes are the
+            # inputs' own.  So they are handed to the main stream (ONE C call, regtr_encoder_fwd) the moment level 0's conv table is
+            # enqueued, and run (0.25 ms of GPU time) next to pyramid levels 1-3 on the side stream.  Only with the pyramid itself enqueued
+            # from C (regtr_pyramid_fwd, two phases): paced by Python op calls (0.55 ms of host time), the host -- not the GPU -- bounds this
+            # stretch and the extra call in the middle costs what the overlap returns (measured: 2.76 vs 2.46 ms per pair).
             main = torch.cuda.current_stream()
             side = self._side_stream(dev)
             ev0 = torch.cuda.Event()
@@ -298,8 +301,8 @@ class RegTR(nn.Module):
                     carried['x'], carried['skips'] = self.kpf_encoder(feats0, meta0, 0, n_l0)
             with torch.cuda.stream(side):
                 state = self.preprocessor.enqueue(clouds, level0_event=ev0, after_level0=level0_blocks)
-            kpconv_meta = self.preprocessor.finish(state)
-            self._record_meta(kpconv_meta, main)                     # (small batches are sized at full capacity: finish() cannot ask for a rebuild)
+            kpconv_meta = self.preprocessor.finish(state)           # (small batches are sized at full capacity: no rebuild can be asked for)
+            self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(carried['x'], kpconv_meta, n_l0, None, carried['skips'])
         else:
