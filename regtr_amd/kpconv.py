@@ -84,13 +84,16 @@ class Preprocessor(nn.Module):
             meta = self.finish(self.enqueue(pts))
         return meta
 
-    def enqueue(self, pts: List[torch.Tensor], level0_event=None, after_level0=None):
+    def enqueue(self, pts: List[torch.Tensor], level0_event=None, after_level0=None, launch_stream=None):
         """Enqueues the whole pyramid on the current stream without touching the host (default order only; the parity mode's KD-tree
         reads its row widths back).  level0_event: recorded as soon as level 0's conv table is complete -- everything the level-0
         blocks need (RegTR.forward starts them on its main stream while the rest of the pyramid is still being built on this one).
         after_level0(meta0): called right after that event, BEFORE the rest of the pyramid is enqueued -- small batches, where the
         pyramid's ~80 launches are paced by the host: the level-0 blocks must be in the main stream's queue before the host spends
         another 0.4 ms enqueuing levels 1-3, or there is nothing for them to overlap with.
+        launch_stream (one-call pyramid only): the pyramid's launches go to THAT stream while every buffer is allocated on the current
+        one -- the caller's main stream, which waits for the pyramid's `done` event before it reads or frees any of them, so no tensor
+        needs a record_stream (25 calls of ~5 us on the critical path of a one-pair forward).
         -> state for finish() / level0_meta()."""
         cfg = self.cfg
         limits = cfg.neighborhood_limits
@@ -122,7 +125,9 @@ class Preprocessor(nn.Module):
         if ref_order and (nb_order or key_mode):
             raise ValueError('kpconv_ref_row_order reproduces the CPU Preprocessor; kpconv_neighbor_order = index / kpconv_voxel_key = floor are the GPU one')
         if self.one_call_ok(n0):
-            return self._enqueue_one_call(points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0)
+            return self._enqueue_one_call(points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0, launch_stream)
+        if launch_stream is not None:
+            raise RuntimeError('Preprocessor.enqueue: launch_stream is served by the one-call pyramid only (one_call_ok)')
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
@@ -212,7 +217,7 @@ class Preprocessor(nn.Module):
             self._plan = (key, plan)
         return self._plan[1]
 
-    def _enqueue_one_call(self, points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0):
+    def _enqueue_one_call(self, points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0, launch_stream=None):
         L = _lib.lib()
         dev = points.device
         plan = self._level_plan()
@@ -240,21 +245,33 @@ class Preprocessor(nn.Module):
         if nb == 0:
             raise RuntimeError('regtr_pyramid_fwd does not serve this pyramid (regtr_pyramid_supported)')
         ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        st = _lib.stream()
+        seg_pin = torch.empty((n_lv, n_clouds + 1), dtype=torch.int32, pin_memory=True)
+        if launch_stream is not None:
+            launch_stream.wait_stream(torch.cuda.current_stream())       # the inputs, and whatever last used the buffers just allocated
+            st = launch_stream.cuda_stream
+        else:
+            st = _lib.stream()
         if level0_event is not None and plan[0][0]:
             _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 1, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
-            level0_event.record()
+            level0_event.record(launch_stream) if launch_stream is not None else level0_event.record()
             if after_level0 is not None:
                 after_level0({'points': [points], '_neighbors_i32': [lv_conv[0]], '_seg_off': [seg], '_lens_host': [lens0]})
             _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 2, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
         else:
             _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 0, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
-        seg_pin = torch.empty((n_lv, n_clouds + 1), dtype=torch.int32, pin_memory=True)
-        seg_pin.copy_(torch.stack(lv_seg), non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
+        import contextlib
+        with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
+            stacked = torch.stack(lv_seg)
+            seg_pin.copy_(stacked, non_blocking=True)
+            # (stack_lengths of every level, kpconv.py:383: on the device, in front of `done` -- finish() then uploads nothing)
+            stack_lengths = (stacked[:, 1:] - stacked[:, :-1]).long()
+            done = torch.cuda.Event()
+            done.record()
+        if launch_stream is not None:
+            stack_lengths.record_stream(torch.cuda.current_stream())     # the one tensor of kpconv_meta allocated on the launch stream
         return {'lens0': lens0, 'device': dev, 'ref_order': False, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
-                'lv_pool': lv_pool, 'lv_width': lv_width, 'lv_cap': lv_cap, 'seg_pin': seg_pin, 'done': done, '_ws': ws}
+                'lv_pool': lv_pool, 'lv_width': lv_width, 'lv_cap': lv_cap, 'seg_pin': seg_pin, 'done': done, '_ws': ws,
+                'stack_lengths': stack_lengths}
 
     @staticmethod
     def level0_meta(state):
@@ -287,7 +304,9 @@ class Preprocessor(nn.Module):
                 '_seg_off': lv_seg, '_lens_host': [], '_neighbors_i32': [], '_pools_i32': [], '_pool_width': []}
         want64 = bool(cfg.get('kpconv_meta_int64', False))
         # stack_lengths of every level in one upload (they are already on the host) instead of two small kernels per level
-        stack_lengths = torch.from_numpy(np.diff(seg_host, axis=1).astype(np.int64)).to(device)
+        stack_lengths = state.get('stack_lengths')
+        if stack_lengths is None:
+            stack_lengths = torch.from_numpy(np.diff(seg_host, axis=1).astype(np.int64)).to(device)
         for l in range(len(lv_points)):
             n_l = int(seg_host[l, -1])
             n_next = int(seg_host[l + 1, -1]) if l + 1 < len(lv_points) else 0
@@ -526,9 +545,15 @@ class KPFEncoder(nn.Module):
                     and x.shape[0] > 0)
 
     def _block_table(self):
-        """ctypes array of regtr_encoder_block_t for the blocks, rebuilt when a parameter (version / storage) changes; the tensors behind
-        the pointers are kept alive by the blocks' weight caches."""
-        key, rows = [], []
+        """ctypes array of regtr_encoder_block_t for the blocks, rebuilt when a parameter changes (storage address or version: a cheap
+        fingerprint per forward); the tensors behind the pointers are kept alive by the blocks' weight caches."""
+        fp = []
+        for prm in self.parameters():
+            fp.append(prm.data_ptr()); fp.append(prm._version)
+        fp = tuple(fp)
+        if getattr(self, '_table', None) is not None and self._table[0] == fp:
+            return self._table[1]
+        rows = []
         for blk in self.encoder_blocks:
             kp = blk.KPConv
             ws = [None, None, None, None]
@@ -540,29 +565,26 @@ class KPFEncoder(nn.Module):
                     if isinstance(u, UnaryBlock):
                         ws[i] = _prepared(u._cache, 'w', u.mlp.weight, lambda w: ops.SplitWeight(w, 'nk'))
             rows.append((blk, kind, ws))
-            key += [(id(w), w.kn.data_ptr()) for w in ws if w is not None] + [kp.kernel_points.data_ptr(), kp.kernel_points._version]
-        key = tuple(key)
-        if getattr(self, '_table', None) is None or self._table[0] != key:
-            arr = (_lib.EncoderBlock * len(rows))()
-            keep = []
-            for e, (blk, kind, ws) in zip(arr, rows):
-                kp = blk.KPConv
-                e.kind, e.strided, e.layer = kind, int('strided' in blk.block_name), int(blk.layer_ind)
-                e.n_kp, e.extent = int(kp.K), float(kp.KP_extent)
-                e.kernel_points = _lib.ptr(kp.kernel_points.detach())
-                for name, w in zip(('unary1', 'conv', 'unary2', 'shortcut'), ws):
-                    f = getattr(e, name)
-                    if w is None:
-                        f.kn = f.planes = f.planes16 = None
-                        f.N = f.K = 0
-                        continue
-                    f.kn = _lib.ptr(w.kn)
-                    f.planes = _lib.bptr(w.planes) if w.planes is not None else None
-                    f.planes16 = _lib.bptr(w.planes16) if (w.planes is not None and w.f16_ok) else None
-                    f.N, f.K = int(w.N), int(w.K)
-                    keep.append(w)
-            self._table = (key, arr, keep)
-        return self._table[1]
+        arr = (_lib.EncoderBlock * len(rows))()
+        keep = []
+        for e, (blk, kind, ws) in zip(arr, rows):
+            kp = blk.KPConv
+            e.kind, e.strided, e.layer = kind, int('strided' in blk.block_name), int(blk.layer_ind)
+            e.n_kp, e.extent = int(kp.K), float(kp.KP_extent)
+            e.kernel_points = _lib.ptr(kp.kernel_points.detach())
+            for name, w in zip(('unary1', 'conv', 'unary2', 'shortcut'), ws):
+                f = getattr(e, name)
+                if w is None:
+                    f.kn = f.planes = f.planes16 = None
+                    f.N = f.K = 0
+                    continue
+                f.kn = _lib.ptr(w.kn)
+                f.planes = _lib.bptr(w.planes) if w.planes is not None else None
+                f.planes16 = _lib.bptr(w.planes16) if (w.planes is not None and w.f16_ok) else None
+                f.N, f.K = int(w.N), int(w.K)
+                keep.append(w)
+        self._table = (fp, arr, keep)
+        return arr
 
     def _forward_one_call(self, x, meta, start, stop):
         L = _lib.lib()

@@ -182,6 +182,14 @@ class RegTR(nn.Module):
             ent = self._cache[key] = (torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32).pin_memory())
         return ent
 
+    def _ones(self, n, dev):
+        """RegTR's input features (regtr.py:136: ones, one per point) as a view of a cached buffer: constant data, a fill kernel and an
+        allocation less per forward."""
+        ent = self._cache.get(('ones', dev))
+        if ent is None or ent.shape[0] < n:
+            ent = self._cache[('ones', dev)] = torch.ones((max(n, 1) * 5 // 4 + 16, 1), dtype=torch.float32, device=dev)
+        return ent[:n]
+
     def _side_stream(self, dev):
         return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
 
@@ -289,20 +297,13 @@ class RegTR(nn.Module):
             main = torch.cuda.current_stream()
             side = self._side_stream(dev)
             ev0 = torch.cuda.Event()
-            side.wait_stream(main)
             carried = {}
 
-            def level0_blocks(meta0):
-                for t in (meta0['points'][0], meta0['_neighbors_i32'][0], meta0['_seg_off'][0]):
-                    t.record_stream(main)
-                with torch.cuda.stream(main):
-                    main.wait_event(ev0)
-                    feats0 = torch.ones_like(meta0['points'][0][:, 0:1])
-                    carried['x'], carried['skips'] = self.kpf_encoder(feats0, meta0, 0, n_l0)
-            with torch.cuda.stream(side):
-                state = self.preprocessor.enqueue(clouds, level0_event=ev0, after_level0=level0_blocks)
+            def level0_blocks(meta0):                      # (runs on the main stream: every buffer of the pyramid was allocated there too)
+                main.wait_event(ev0)
+                carried['x'], carried['skips'] = self.kpf_encoder(self._ones(meta0['points'][0].shape[0], dev), meta0, 0, n_l0)
+            state = self.preprocessor.enqueue(clouds, level0_event=ev0, after_level0=level0_blocks, launch_stream=side)
             kpconv_meta = self.preprocessor.finish(state)           # (small batches are sized at full capacity: no rebuild can be asked for)
-            self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(carried['x'], kpconv_meta, n_l0, None, carried['skips'])
         else:

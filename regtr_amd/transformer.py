@@ -151,9 +151,24 @@ class TransformerCrossEncoder(nn.Module):
         return bool(ctx.f16_pair and not ctx.force_x3 and l0.gemm_planes >= 2 and ops.f16_pair_ok(n, 3 * D, D) and ops.f16_pair_ok(n, D, D)
                     and ops.f16_pair_ok(n, F, D) and ops.f16_pair_ok(n, D, F))
 
+    def _fingerprint(self):
+        """Cheap identity of everything the cached tables point at: (storage address, version) of every parameter -- ~100 attribute reads,
+        against rebuilding 108 pointers through the weight caches (0.2 ms of a 2.5 ms one-pair forward, tools/host_profile.py)."""
+        fp = []
+        for prm in self.parameters():
+            fp.append(prm.data_ptr()); fp.append(prm._version)
+        return tuple(fp)
+
     def _param_table(self, f16=False):
         """(ctypes array of the layers' device pointers in regtr_cross_encoder_fwd's order, ctypes array of the norm eps) -- rebuilt only
-        when a pointer changes; the tensors behind the pointers are kept alive by the modules / the layers' weight caches."""
+        when a parameter changes (address or version); the tensors behind the pointers are kept alive by the modules / the layers' weight
+        caches.  -> (None, None) for f16 when a weight lies beyond the format's range."""
+        fp = self._fingerprint()
+        if self._table is None or self._table[0] != fp:
+            self._table = (fp, {})
+        tables = self._table[1]
+        if f16 in tables:
+            return tables[f16]
         ptrs, eps = [], []
         if f16:       # every weight inside the format's range (audited once per weight version, SplitWeight.f16_ok); else: the bf16 planes
             for layer in self.layers:
@@ -162,7 +177,8 @@ class TransformerCrossEncoder(nn.Module):
                                ('ca_in', m['multihead_attn'].in_proj_weight), ('ca_out', m['multihead_attn'].out_proj.weight),
                                ('l1', m['linear1'].weight), ('l2', m['linear2'].weight)):
                     if not layer._wt(tag, w).f16_ok:
-                        return None, None
+                        tables[f16] = (None, None)
+                        return tables[f16]
         for layer in self.layers:
             m = layer._modules
             sa, ca = m['self_attn'], m['multihead_attn']
@@ -175,13 +191,11 @@ class TransformerCrossEncoder(nn.Module):
                       pl(layer._wt('ca_out', ca.out_proj.weight)), ca.out_proj.bias,
                       n3.weight, n3.bias, pl(layer._wt('l1', l1.weight)), l1.bias, pl(layer._wt('l2', l2.weight)), l2.bias):
                 ptrs.append(t.data_ptr())
-        key = (tuple(ptrs), tuple(eps))
-        if self._table is None or self._table[0] != key:
-            for layer in self.layers:                       # checked once per table: everything the C side dereferences is float32 / bytes on one GPU
-                for prm in layer.parameters():
-                    _lib.ptr(prm.detach())
-            self._table = (key, (ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_float * len(eps))(*eps))
-        return self._table[1], self._table[2]
+        for layer in self.layers:                       # checked once per table: everything the C side dereferences is float32 / bytes on one GPU
+            for prm in layer.parameters():
+                _lib.ptr(prm.detach())
+        tables[f16] = ((ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_float * len(eps))(*eps))
+        return tables[f16]
 
     def _forward_one_call(self, x, pe, seg_off, kv_self, kv_cross, max_len, outs):
         L = _lib.lib()
