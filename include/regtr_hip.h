@@ -29,7 +29,6 @@
  *   regtr_gemm_stream         nn.Linear call sites                kpconv_blocks.py:557, regtr.py:145,432-436, transformers.py:197-238
  *   regtr_block_tail          ResnetBottleneckBlock tail (unary2 + unary_shortcut + sum + LeakyReLU), SimpleBlock after its gather
  *                                                                 kpconv_blocks.py:727-741, 590-646
- *   regtr_pyramid_fwd         PreprocessorGPU.forward (levels sequenced) models/backbone_kpconv/kpconv.py:426-537
  *   regtr_encoder_fwd         KPFEncoder.forward (blocks sequenced) models/backbone_kpconv/kpconv.py:81-88, kpconv_blocks.py:632-646,706-741
  *   regtr_layernorm           nn.LayerNorm (+ with_pos_embed)     transformers.py:116-119,194-195,213-215,232
  *   regtr_posemb_sine         PositionEmbeddingCoordsSine.forward models/transformer/position_embedding.py:29-50
@@ -317,31 +316,6 @@ int regtr_cross_encoder_fwd(const float* x, int n_tok, int d_model, int d_ff, in
                             const float* final_beta, float final_eps, int return_intermediate, const float* pe,
                             const int* seg_off, const int* kv_self, const int* kv_cross, int n_clouds, int max_len,
                             int gemm_planes, int attn_precision, void* ws, size_t ws_bytes, float* outs, int* status, void* stream);
-
-/* The preprocessing pyramid of a SMALL batch (kpconv.py:426-537 PreprocessorGPU.forward / :298-414 Preprocessor.forward) enqueued by one
- * call per phase: per level regtr_cellgrid_build -> conv table (regtr_radius_query) -> regtr_grid_subsample_ordered -> pool table, with
- * the arguments regtr_amd/kpconv.py passes them one by one (bit-identical tables and points).  For a pair or two per forward the ~70
- * launches are paced by the host; from C they go out 2-3x faster, and in two phases so that the level-0 encoder blocks can start in
- * between.  Regime (supported()): fewer than 262144 input points -- every level at the input capacity, per-query radius kernel.
- * HOST-side descriptor of level l (level l + 1's points / seg_off ARE level l's points_next / seg_next): */
-typedef struct {
-    float radius;           /* conv radius of the level */
-    float dl;               /* voxel size of the subsampling onto the next level (strided) */
-    int K;                  /* table width (neighborhood_limits[l]) */
-    int has_conv, strided;
-    int cap, cap_next;      /* row capacities of this level's / the next level's arrays */
-    const float* points;    /* [cap, 3] */
-    const int* seg_off;     /* [n_clouds + 1] live offsets (device) */
-    int* conv_idx;          /* out [cap, K] (has_conv) */
-    float* points_next;     /* out [cap_next, 3] (strided) */
-    int* seg_next;          /* out [n_clouds + 1] (strided) */
-    int* pool_idx;          /* out [cap_next, K] (strided) */
-} regtr_pyramid_level_t;
-int regtr_pyramid_supported(const regtr_pyramid_level_t* levels, int n_levels, int n_clouds);
-size_t regtr_pyramid_ws_bytes(const regtr_pyramid_level_t* levels, int n_levels, int n_clouds);
-/* phase 0: everything; 1: level 0's cell grid + conv table only; 2: everything after phase 1 (same ws, untouched in between) */
-int regtr_pyramid_fwd(const regtr_pyramid_level_t* levels, int n_levels, int n_clouds, int order, int key_mode, int phase, void* ws,
-                      size_t ws_bytes, void* stream);
 
 /* The KPConv encoder's blocks (kpconv.py:81-88 KPFEncoder.forward over kpconv_blocks.py:632-646 SimpleBlock.forward and :706-741
  * ResnetBottleneckBlock.forward) enqueued by ONE call, for the SMALL-batch regime: a pair or two per forward -- the reference's own

@@ -38,12 +38,6 @@ class EncoderLevel(_c.Structure):
     _fields_ = [('points', _P), ('n', _I), ('conv_idx', _P), ('pool_idx', _P), ('K', _I), ('pool_width', _I), ('seg_off', _P), ('max_len', _I)]
 
 
-class PyramidLevel(_c.Structure):
-    """regtr_pyramid_level_t."""
-    _fields_ = [('radius', _F), ('dl', _F), ('K', _I), ('has_conv', _I), ('strided', _I), ('cap', _I), ('cap_next', _I), ('points', _P),
-                ('seg_off', _P), ('conv_idx', _P), ('points_next', _P), ('seg_next', _P), ('pool_idx', _P)]
-
-
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
 ABI_VERSION = 10         # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
 
@@ -99,9 +93,6 @@ SIGNATURES = {
     'regtr_cross_encoder_supported': (_I, [_I, _I, _I, _I]),
     'regtr_cross_encoder_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_cross_encoder_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _Z, _P, _P, _P]),
-    'regtr_pyramid_supported': (_I, [_P, _I, _I]),
-    'regtr_pyramid_ws_bytes': (_Z, [_P, _I, _I]),
-    'regtr_pyramid_fwd': (_I, [_P, _I, _I, _I, _I, _I, _P, _Z, _P]),
     'regtr_encoder_supported': (_I, [_P, _I, _P, _I, _I, _I, _I]),
     'regtr_encoder_ws_bytes': (_Z, [_P, _I, _P, _I, _I, _I, _I, _I]),
     'regtr_encoder_fwd': (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _I, _F, _F, _P, _Z, _P, _P]),
@@ -109,7 +100,7 @@ SIGNATURES = {
     'regtr_weighted_procrustes': (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
 }
 
-COMPOSITE = ('regtr_pyramid_fwd', 'regtr_encoder_fwd', 'regtr_cross_encoder_fwd')      # bound through a GIL-releasing handle (see _load)
+COMPOSITE = ('regtr_encoder_fwd', 'regtr_cross_encoder_fwd')      # bound through a GIL-releasing handle (see _load)
 
 _ERR = {-1: 'kernel launch failed', -2: 'invalid argument', -3: 'workspace too small'}
 

@@ -14,7 +14,7 @@ VARIANT = os.environ.get('REGTR_VARIANT', '')
 VARIANT_FLAGS = os.environ.get('REGTR_VARIANT_FLAGS', '').split()
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-SOURCES = ['preprocess.hip', 'ref_order.hip', 'kpconv.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_stream.hip', 'block_tail.hip', 'norm.hip', 'attention.hip', 'cross_encoder.hip', 'encoder.hip', 'pyramid.hip', 'procrustes.hip']
+SOURCES = ['preprocess.hip', 'ref_order.hip', 'kpconv.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_stream.hip', 'block_tail.hip', 'norm.hip', 'attention.hip', 'cross_encoder.hip', 'encoder.hip', 'procrustes.hip']
 # bit-level parity of the float32 distance / voxel arithmetic with the reference's SSE2 build needs no contraction
 # kpconv.hip: SLP-packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves and blocks v_add_f32_dpp fusion
 EXTRA = {'preprocess.hip': ['-ffp-contract=off'], 'ref_order.hip': ['-ffp-contract=off'], 'kpconv.hip': ['-fno-slp-vectorize']}

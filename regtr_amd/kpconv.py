@@ -84,16 +84,10 @@ class Preprocessor(nn.Module):
             meta = self.finish(self.enqueue(pts))
         return meta
 
-    def enqueue(self, pts: List[torch.Tensor], level0_event=None, after_level0=None, launch_stream=None):
+    def enqueue(self, pts: List[torch.Tensor], level0_event=None):
         """Enqueues the whole pyramid on the current stream without touching the host (default order only; the parity mode's KD-tree
         reads its row widths back).  level0_event: recorded as soon as level 0's conv table is complete -- everything the level-0
         blocks need (RegTR.forward starts them on its main stream while the rest of the pyramid is still being built on this one).
-        after_level0(meta0): called right after that event, BEFORE the rest of the pyramid is enqueued -- small batches, where the
-        pyramid's ~80 launches are paced by the host: the level-0 blocks must be in the main stream's queue before the host spends
-        another 0.4 ms enqueuing levels 1-3, or there is nothing for them to overlap with.
-        launch_stream (one-call pyramid only): the pyramid's launches go to THAT stream while every buffer is allocated on the current
-        one -- the caller's main stream, which waits for the pyramid's `done` event before it reads or frees any of them, so no tensor
-        needs a record_stream (25 calls of ~5 us on the critical path of a one-pair forward).
         -> state for finish() / level0_meta()."""
         cfg = self.cfg
         limits = cfg.neighborhood_limits
@@ -124,10 +118,6 @@ class Preprocessor(nn.Module):
         key_mode = ops.VOXEL_KEY_MODES[key_name]
         if ref_order and (nb_order or key_mode):
             raise ValueError('kpconv_ref_row_order reproduces the CPU Preprocessor; kpconv_neighbor_order = index / kpconv_voxel_key = floor are the GPU one')
-        if self.one_call_ok(n0):
-            return self._enqueue_one_call(points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0, launch_stream)
-        if launch_stream is not None:
-            raise RuntimeError('Preprocessor.enqueue: launch_stream is served by the one-call pyramid only (one_call_ok)')
 
         r_normal = cfg.first_subsampling_dl * cfg.conv_radius                 # kpconv.py:315
         layer_blocks, layer = [], 0
@@ -157,8 +147,6 @@ class Preprocessor(nn.Module):
                     conv_i = grid.query(points, seg, cap, K, order=nb_order)             # :349-351
                 if layer == 0 and level0_event is not None:
                     level0_event.record()
-                    if after_level0 is not None:
-                        after_level0({'points': [points], '_neighbors_i32': [conv_i], '_seg_off': [seg], '_lens_host': [lens0]})
                 if strided:
                     pool_p, pool_seg = ops.grid_subsample(points, seg, cap, dl, key_mode=key_mode, out_cap=cap_next)          # :366 / :213-240
                     pool_i = grid.query(pool_p, pool_seg, cap_next, K, order=nb_order)   # :376
@@ -184,94 +172,6 @@ class Preprocessor(nn.Module):
         done.record()
         return {'lens0': lens0, 'device': device, 'ref_order': ref_order, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
                 'lv_pool': lv_pool, 'lv_width': lv_width, 'lv_cap': lv_cap, 'seg_pin': seg_pin, 'done': done}
-
-    # ---- the same pyramid through ONE C call per phase (regtr_pyramid_fwd, csrc/pyramid.hip): small batches, where the ~70 launches are
-    # paced by the host.  Same entry points, same arguments, same order: bit-identical tables and points.
-    def one_call_ok(self, n0):
-        return bool(ops.use_one_call_pyramid and not self.cfg.get('kpconv_ref_row_order', False) and 0 < n0 < CAPACITY_MIN_POINTS
-                    and n0 < ops.SELF_QUERY_MIN_POINTS and ops.self_query_kernel)
-
-    def _level_plan(self):
-        """[(has_conv, strided, K, radius, dl)] per pyramid level: the control flow of enqueue() / kpconv.py:328-404 without the launches."""
-        cfg = self.cfg
-        key = (tuple(cfg.architecture), tuple(cfg.neighborhood_limits), cfg.first_subsampling_dl, cfg.conv_radius)
-        if getattr(self, '_plan', None) is None or self._plan[0] != key:
-            plan, layer_blocks, layer = [], [], 0
-            r_normal = cfg.first_subsampling_dl * cfg.conv_radius
-            arch = cfg.architecture
-            for block_i, block in enumerate(arch):
-                if 'global' in block or 'upsample' in block:
-                    break
-                if not ('pool' in block or 'strided' in block):
-                    layer_blocks += [block]
-                    if block_i < len(arch) - 1 and not ('upsample' in arch[block_i + 1]):
-                        continue
-                if any('deformable' in b for b in layer_blocks) or 'deformable' in block:
-                    raise NotImplementedError('deformable KPConv is outside the RegTR inference path')
-                strided = 'pool' in block or 'strided' in block
-                plan.append((bool(layer_blocks), bool(strided), int(cfg.neighborhood_limits[layer]), float(r_normal),
-                             float(2 * r_normal / cfg.conv_radius)))
-                r_normal *= 2
-                layer += 1
-                layer_blocks = []
-            self._plan = (key, plan)
-        return self._plan[1]
-
-    def _enqueue_one_call(self, points, seg, lens0, n0, nb_order, key_mode, level0_event, after_level0, launch_stream=None):
-        L = _lib.lib()
-        dev = points.device
-        plan = self._level_plan()
-        n_clouds = len(lens0)
-        lv = (_lib.PyramidLevel * len(plan))()
-        lv_points, lv_seg, lv_conv, lv_pool, lv_width, lv_cap = [], [], [], [], [], []
-        pts, sg = points, seg
-        i32 = dict(dtype=torch.int32, device=dev)
-        for e, (has_conv, strided, K, r, dl) in zip(lv, plan):
-            conv = torch.empty((n0, K), **i32) if has_conv else None
-            nxt = nseg = pool = None
-            if strided:
-                nxt = torch.empty((n0, 3), dtype=torch.float32, device=dev)
-                nseg = torch.empty(n_clouds + 1, **i32)
-                pool = torch.empty((n0, K), **i32)
-            e.radius, e.dl, e.K, e.has_conv, e.strided, e.cap, e.cap_next = r, dl, K, int(has_conv), int(strided), n0, n0
-            e.points, e.seg_off = _lib.ptr(pts), _lib.iptr(sg)
-            e.conv_idx, e.points_next, e.seg_next, e.pool_idx = _lib.iptr(conv), _lib.ptr(nxt), _lib.iptr(nseg), _lib.iptr(pool)
-            lv_points.append(pts); lv_seg.append(sg); lv_conv.append(conv); lv_pool.append(pool); lv_cap.append(n0); lv_width.append((K, K))
-            if not strided:
-                break
-            pts, sg = nxt, nseg
-        n_lv = len(lv_points)
-        nb = L.regtr_pyramid_ws_bytes(lv, n_lv, n_clouds)
-        if nb == 0:
-            raise RuntimeError('regtr_pyramid_fwd does not serve this pyramid (regtr_pyramid_supported)')
-        ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-        seg_pin = torch.empty((n_lv, n_clouds + 1), dtype=torch.int32, pin_memory=True)
-        if launch_stream is not None:
-            launch_stream.wait_stream(torch.cuda.current_stream())       # the inputs, and whatever last used the buffers just allocated
-            st = launch_stream.cuda_stream
-        else:
-            st = _lib.stream()
-        if level0_event is not None and plan[0][0]:
-            _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 1, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
-            level0_event.record(launch_stream) if launch_stream is not None else level0_event.record()
-            if after_level0 is not None:
-                after_level0({'points': [points], '_neighbors_i32': [lv_conv[0]], '_seg_off': [seg], '_lens_host': [lens0]})
-            _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 2, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
-        else:
-            _lib.check(L.regtr_pyramid_fwd(lv, n_lv, n_clouds, nb_order, key_mode, 0, _lib.bptr(ws), nb, st), 'regtr_pyramid_fwd')
-        import contextlib
-        with (torch.cuda.stream(launch_stream) if launch_stream is not None else contextlib.nullcontext()):
-            stacked = torch.stack(lv_seg)
-            seg_pin.copy_(stacked, non_blocking=True)
-            # (stack_lengths of every level, kpconv.py:383: on the device, in front of `done` -- finish() then uploads nothing)
-            stack_lengths = (stacked[:, 1:] - stacked[:, :-1]).long()
-            done = torch.cuda.Event()
-            done.record()
-        if launch_stream is not None:
-            stack_lengths.record_stream(torch.cuda.current_stream())     # the one tensor of kpconv_meta allocated on the launch stream
-        return {'lens0': lens0, 'device': dev, 'ref_order': False, 'lv_points': lv_points, 'lv_seg': lv_seg, 'lv_conv': lv_conv,
-                'lv_pool': lv_pool, 'lv_width': lv_width, 'lv_cap': lv_cap, 'seg_pin': seg_pin, 'done': done, '_ws': ws,
-                'stack_lengths': stack_lengths}
 
     @staticmethod
     def level0_meta(state):

@@ -418,8 +418,6 @@ PREAPPLY_MIN_ROWS = 8192        # (a pair or two per forward is launch-bound: th
 use_one_call_cross_encoder = devflags.on('REGTR_ONE_CALL_XENC')
 # the encoder's blocks enqueued by one C call (regtr_encoder_fwd) in the small-batch regime (< 65536 level-0 rows) instead of ~130 op calls
 use_one_call_encoder = devflags.on('REGTR_ONE_CALL_ENC')
-# ... and the preprocessing pyramid of a small batch (< 262144 input points) by one C call per phase (regtr_pyramid_fwd) instead of ~14 op calls
-use_one_call_pyramid = devflags.on('REGTR_ONE_CALL_PYR')
 force_f32_gemm = False      # tests / A-B runs: route every GEMM to the exact-f32 MFMA kernel
 force_x3_gemm = False       # tests: route every supported shape to the split kernel, also where it is not the faster one
 

@@ -41,7 +41,6 @@ class PositionEmbeddingCoordsSine(nn.Module):
 # A-B switch and size gate of the two-stream forward (RegTR._forward)
 overlap_preprocessing = devflags.on('REGTR_OVERLAP')          # (read only under REGTR_DEV=1)
 OVERLAP_MIN_POINTS = 131072
-SMALL_OVERLAP = devflags.on('REGTR_SMALL_OVERLAP')      # the level-0 blocks of a small batch under the host's enqueue of pyramid levels 1-3
 
 
 class CorrespondenceRegressor(nn.Module):
@@ -286,30 +285,12 @@ class RegTR(nn.Module):
                 self._record_meta(kpconv_meta, main)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
-        elif (two_streams and SMALL_OVERLAP and n0 < ops.PRENORM_MIN_ROWS and ops.use_one_call_encoder and self.preprocessor.one_call_ok(n0)
-              and context.current().gather_records is None and context.current().gemm_records is None):
-            # A pair or two per forward (the reference's own mode): the encoder cannot start before the level sizes have been read back
-            # behind the pyramid (~70 launches of 2-30 us, 0.45 ms of GPU time).  The level-0 blocks need no read-back: their sizes are the
-            # inputs' own.  So they are handed to the main stream (ONE C call, regtr_encoder_fwd) the moment level 0's conv table is
-            # enqueued, and run (0.25 ms of GPU time) next to pyramid levels 1-3 on the side stream.  Only with the pyramid itself enqueued
-            # from C (regtr_pyramid_fwd, two phases): paced by Python op calls (0.55 ms of host time), the host -- not the GPU -- bounds this
-            # stretch and the extra call in the middle costs what the overlap returns (measured: 2.76 vs 2.46 ms per pair).
-            main = torch.cuda.current_stream()
-            side = self._side_stream(dev)
-            ev0 = torch.cuda.Event()
-            carried = {}
-
-            def level0_blocks(meta0):                      # (runs on the main stream: every buffer of the pyramid was allocated there too)
-                main.wait_event(ev0)
-                carried['x'], carried['skips'] = self.kpf_encoder(self._ones(meta0['points'][0].shape[0], dev), meta0, 0, n_l0)
-            state = self.preprocessor.enqueue(clouds, level0_event=ev0, after_level0=level0_blocks, launch_stream=side)
-            kpconv_meta = self.preprocessor.finish(state)           # (small batches are sized at full capacity: no rebuild can be asked for)
-            batch['kpconv_meta'] = kpconv_meta
-            feats_un, _ = self.kpf_encoder(carried['x'], kpconv_meta, n_l0, None, carried['skips'])
         else:
             kpconv_meta = self.preprocessor(clouds)
             batch['kpconv_meta'] = kpconv_meta
-            feats0 = torch.ones_like(kpconv_meta['points'][0][:, 0:1])
+            # (small batches -- a pair or two per forward -- run ONE stream: the level-0 blocks overlapped with pyramid levels 1-3 on a second
+            #  stream, with the pyramid sequenced from C in two phases, measured 2.46 vs 2.38 ms per pair: docs/NEGATIVES.md, round 5)
+            feats0 = self._ones(kpconv_meta['points'][0].shape[0], dev)
             if ev: ev[1].record()
             feats_un, _ = self.kpf_encoder(feats0, kpconv_meta)
         slens_c = kpconv_meta['_lens_host'][-1]
