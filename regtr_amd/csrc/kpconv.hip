@@ -264,6 +264,9 @@ typedef float rg_f32x2 __attribute__((ext_vector_type(2)));
 #ifndef RG_MG_WAVES_PER_EU
 #define RG_MG_WAVES_PER_EU 3
 #endif
+#ifndef RG_MG_CHAINS
+#define RG_MG_CHAINS 1             // development A-B (REGTR_VARIANT_FLAGS=-DRG_MG_CHAINS=2): see the MFMA loop
+#endif
 // PRE: g.s_xyzf holds (x, y, z, positivity flag) records and the features are final (no InstanceNorm fold) -- the launcher's choice
 // when the caller passes `s_xyzf` and no x_stats.  Per neighbour ONE 16-byte load replaces three coordinate dwords (plus the flag):
 // PMC on the level-0 launch showed the texture-address path 76 % busy, 148 of ~260 lines per query being those scattered dwords,
@@ -418,11 +421,28 @@ __global__ void __launch_bounds__(GATHER_WAVES * RG_WAVE, RG_MG_WAVES_PER_EU) k_
             floatx4 acc[V];
 #pragma unroll
             for (int v = 0; v < V; v++) acc[v] = floatx4{0.f, 0.f, 0.f, 0.f};
+#if RG_MG_CHAINS == 2
+            // probe (round 5): the J dependent MFMAs of a channel slice as TWO independent accumulator chains (even / odd
+            // neighbour groups), added at the end -- does the issue-stall share fall?  (profiles/r05_gather_chains.md; not the product build)
+            floatx4 accb[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) accb[v] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < J; j++)
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    if (j & 1) accb[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], rg_comp(xv[j], v), accb[v], 0, 0, 0);
+                    else acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], rg_comp(xv[j], v), acc[v], 0, 0, 0);
+                }
+#pragma unroll
+            for (int v = 0; v < V; v++) acc[v] += accb[v];
+#else
 #pragma unroll
             for (int j = 0; j < J; j++)
 #pragma unroll
                 for (int v = 0; v < V; v++)
                     acc[v] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[j], rg_comp(xv[j], v), acc[v], 0, 0, 0);
+#endif
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 vec o;
