@@ -350,8 +350,8 @@ typedef struct {
     const int* seg_off;     /* [n_clouds + 1] */
     int max_len;            /* longest cloud of the level */
 } regtr_encoder_level_t;
-/* supported(): the regime (fewer than 65536 level-0 rows: none of the large-batch kernel forms applies) and the shapes; otherwise issue
- * the launches one by one.  x_in [rows of block `first`'s level, its input width] -> out [rows of block `last - 1`'s level, its width];
+/* supported(): the shapes; the CALLER keeps the call to its small-batch regime (regtr_amd/ops.py SMALL_REGIME_ROWS = 131072 level-0 rows:
+ * below it no large-batch kernel form applies -- which is the routing this function implements); otherwise issue the launches one by one.  x_in [rows of block `first`'s level, its input width] -> out [rows of block `last - 1`'s level, its width];
  * blocks [first, last).  f16_pair: contractions in the f16 pair format where planes16 exists and the kernel serves the shape (what
  * cfg.compute_dtype 'fp32' runs); ws: regtr_encoder_ws_bytes(...) bytes for the same arguments. */
 int regtr_encoder_supported(const regtr_encoder_block_t* blocks, int n_blocks, const regtr_encoder_level_t* levels, int n_levels,

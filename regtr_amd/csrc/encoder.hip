@@ -10,9 +10,9 @@
 // routing rules of regtr_amd/kpconv.py + regtr_amd/ops.py for this regime, so the outputs are bit-identical to the op-by-op path
 // (tests/test_gpu_model.py::test_one_call_encoder_equals_op_by_op).
 //
-// The regime (regtr_encoder_supported): fewer than 65536 level-0 rows.  Below that none of the large-batch forms applies (packed support
-// records / pre-normalised gather: >= 65536 rows; one-shot strip GEMM, block tails from input moments, first-block tail: >= 131072 rows;
-// the in-place normalisation before unary2: >= 8192 rows AND > 64 channels, which no level of such a batch reaches), so the routing is:
+// The regime: the caller's SMALL-batch regime (regtr_amd/ops.py SMALL_REGIME_ROWS: fewer than 131072 level-0 rows), where none of the
+// large-batch forms applies (packed support records / pre-normalised gather, one-shot strip GEMM, block tails from input moments,
+// first-block tail); the in-place normalisation before unary2 (>= 8192 rows AND > 64 channels) is implemented.  So the routing is:
 //   Linear            regtr_gemm_x3 (tiled split GEMM) when regtr_gemm_x3_preferred and (N >= 64 or no folded operand), else regtr_gemm_f32;
 //                     InstanceNorm statistics of the result from the GEMM epilogue (regtr_instnorm_finalize_tiles) when the launch has a
 //                     statistics tile, else regtr_instnorm_stats on the result
@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int ENC_SMALL_ROWS = 65536;       // regtr_amd/ops.py PRENORM_MIN_ROWS: the first large-batch gate a growing forward meets
+constexpr int ENC_SMALL_ROWS = 1 << 22;     // a guard only: the CALLER keeps this path to its small-batch regime (regtr_amd/ops.py SMALL_REGIME_ROWS)
 constexpr int ENC_PREAPPLY_ROWS = 8192;     // regtr_amd/ops.py PREAPPLY_MIN_ROWS
 
 struct Enc {

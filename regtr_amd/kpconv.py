@@ -293,6 +293,7 @@ class _LevelView:
         self.max_pre = max(meta['_lens_host'][layer])
         self.seg_post = meta['_seg_off'][layer + 1] if strided else self.seg_pre
         self.max_post = max(meta['_lens_host'][layer + 1]) if strided else self.max_pre
+        self.small = meta['points'][0].shape[0] < ops.SMALL_REGIME_ROWS       # the small-batch regime (ops.SMALL_REGIME_ROWS)
 
 
 class SimpleBlock(nn.Module):
@@ -312,7 +313,7 @@ class SimpleBlock(nn.Module):
     def forward(self, x, meta):
         v = _LevelView(meta, self.layer_ind, 'strided' in self.block_name)
         # one input feature per point (RegTR's ones): (x, y, z, feature) records, one 16-byte load per neighbour in the gather
-        xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather and x.shape[0] >= ops.PRENORM_MIN_ROWS) else None
+        xyzf = torch.cat((v.s_pts, x), dim=1) if (x.shape[1] == 1 and ops.prenorm_gather and x.shape[0] >= ops.PRENORM_MIN_ROWS and not v.small) else None
         kp = self.KPConv
         if x.shape[1] == 1 and ops.first_block_ok(v.q_pts.shape[0], 1, kp.K, kp.out_channels):
             # contraction + InstanceNorm + LReLU in one pass over the gather's 16-float rows (csrc/block_tail.hip)
@@ -351,7 +352,7 @@ class ResnetBottleneckBlock(nn.Module):
         xyzf = None
         if isinstance(self.unary1, UnaryBlock):
             x, x_st = self.unary1.linear(features, v.seg_pre, v.max_pre)
-            if ops.prenorm_gather and x.shape[1] <= 256 and x.shape[0] >= ops.PRENORM_MIN_ROWS:   # (small batches: launch-bound, fold)
+            if ops.prenorm_gather and x.shape[1] <= 256 and x.shape[0] >= ops.PRENORM_MIN_ROWS and not v.small:   # (small batches: launch-bound, fold)
                 xyzf = torch.empty((x.shape[0], 4), dtype=torch.float32, device=x.device)
                 ops.instnorm_apply(x, v.seg_pre, v.max_pre, x_st, lrelu=True, out=x, row_xyz=v.s_pts, row_positive=xyzf)
                 x_st = None
@@ -441,7 +442,7 @@ class KPFEncoder(nn.Module):
         ctx = context.current()
         return bool(ops.use_one_call_encoder and ctx.gather_records is None and ctx.gemm_records is None and ctx.f16_range_log is None
                     and not ops.force_f32_gemm and not ops.force_x3_gemm and ops.use_tile_info and ops.preapply_unary2 == 1
-                    and meta['points'][0].shape[0] < ops.PRENORM_MIN_ROWS and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                    and meta['points'][0].shape[0] < ops.SMALL_REGIME_ROWS and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
                     and x.shape[0] > 0)
 
     def _block_table(self):
