@@ -1059,6 +1059,198 @@ __global__ void __launch_bounds__(64 * MW, 2) k_gemm_x3d(X3Args g)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 64 x 64 tiles of SMALL problems (a pair or two per forward), operand pipeline THREE k-tiles deep (round 5).
+// k_gemm_x3 issues the loads of tile t + 1 before the MFMAs of tile t and meets a __syncthreads() -- s_waitcnt vmcnt(0) -- right
+// behind them, so every k-tile pays a full memory round trip: a K = 256 product is ~10 us of which 0.2 us per tile are MFMAs, and with a few
+// dozen workgroups on 256 CUs nothing else hides it.  69 such launches are a third of a one-pair forward's GPU time.  Here BOTH operands
+// arrive by LDS-DMA (raw float32 A rows, XOR-swizzled like k_gemm_x3d's; weight planes as in k_gemm_x3) into a FOUR-slot ring, the DMA of
+// tile t + 3 is issued while tile t is multiplied, and the one barrier per k-tile is preceded by a COUNTED wait -- vmcnt(2 tiles' worth) --
+// that leaves tiles t + 1 and t + 2 in flight (the DMA instructions are inline asm: the compiler neither tracks nor waits for them).  A is
+// split into its planes at fragment time by the wave that multiplies it (twice per element: the two column waves of a row block; VALU is idle
+// here).  No folded InstanceNorm operand (that launch stays on k_gemm_x3); statistics epilogue and split-K partial products as there.
+template <bool SOUT, int NP, int FMT>
+__global__ void __launch_bounds__(256, 2) k_gemm_x3q(X3Args g)
+{
+    static_assert((FMT == 0 && NP == 3) || (FMT == 1 && NP == 2), "float32-grade formats only: bf16x3 or the f16 pair");
+    constexpr int BM = 64, BN = 64, NT = 256, SLOTS = 4, PD = 3;
+    constexpr int A_BYTES = BM * XBK * 4, B_BYTES = NP * BN * XROW, SLOT_BYTES = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 1024 / 4, NQ = B_BYTES / 1024 / 4, N_TILE = NA + NQ;       // LDS-DMA instructions per wave and k-tile
+    constexpr int STAT_BYTES = SOUT ? 2 * BN * 16 : 0;
+    constexpr int LDS_BYTES = SLOTS * SLOT_BYTES > STAT_BYTES ? SLOTS * SLOT_BYTES : STAT_BYTES;
+    __shared__ __align__(1024) unsigned char sm[LDS_BYTES];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int tile_m, tile_n;
+    {
+        const int nc = g.N / BN, b = blockIdx.x, x = b & 7, q = b >> 3;       // XCD-aware map, as in k_gemm_x3
+        tile_n = q % nc;
+        tile_m = (q / nc) * 8 + x;
+        if (tile_m * BM >= g.M) return;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = blockIdx.z * g.k_chunk;
+    const int k_end = min(g.K, k_begin + g.k_chunk);
+    const int nk = (k_end - k_begin) / XBK;                    // whole k-tiles only (the launcher checks)
+    int s_lo = 0, s_hi = 0, s_lo_begin = 0, s_lo_end = 0;
+    if (SOUT) {
+        if (g.tile_info) {
+            const int4 ti = g.tile_info[tile_m];
+            s_lo = ti.x; s_hi = ti.y; s_lo_begin = ti.z; s_lo_end = ti.w;
+        } else {
+            const int row_last = min(m0 + BM, g.M) - 1;
+            s_lo = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, m0);
+            s_hi = rg_find_segment_wave(g.stat_seg_off, g.n_stat_seg, row_last);
+            s_lo_begin = g.stat_seg_off[s_lo]; s_lo_end = g.stat_seg_off[s_lo + 1];
+        }
+    }
+    // A DMA: instruction q of this wave fills rows 16 wave + 8 q + (lane >> 3), LDS chunk lane & 7 <- source chunk (lane & 7) ^ ((row >> 1) & 7)
+    const float* a_src[NA];
+#pragma unroll
+    for (int q = 0; q < NA; q++) {
+        const int r = wave * (8 * NA) + q * 8 + (lane >> 3);
+        const int row = m0 + r, rc = row < g.M ? row : g.M - 1;    // rows past M compute garbage that the epilogue never stores
+        a_src[q] = g.A + (size_t)rc * g.lda + k_begin + (((lane & 7) ^ ((r >> 1) & 7)) * 4);
+    }
+    const uint16_t* b_src[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const int sidx = (wave * NQ + q) * 64 + lane;
+        const int p = sidx / (BN * 4), r = sidx % (BN * 4), n = r >> 2, kc = (r & 3) ^ ((n >> 2) & 3);
+        b_src[q] = g.Wt + (size_t)p * g.plane + (size_t)(n0 + n) * g.Kp + kc * 8 + k_begin;
+    }
+    const unsigned lds_base = (unsigned)(unsigned long long)(x3_lds_ptr)(&sm[0]);
+    auto dma = [&](int kt, unsigned slot) {
+        const unsigned base = lds_base + slot * SLOT_BYTES;
+#pragma unroll
+        for (int q = 0; q < NA; q++) x3_asm_dma16((const void*)(a_src[q] + kt * XBK), base + (unsigned)(wave * NA + q) * 1024u);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) x3_asm_dma16((const void*)(b_src[q] + kt * XBK), base + A_BYTES + (unsigned)(wave * NQ + q) * 1024u);
+    };
+    // fragment addresses: A row 32 wm + l31, 16-byte chunks 4 ks + 2 hi (+ 1), swizzled; weights as in k_gemm_x3
+    unsigned fa_off[2][2], f_off[2];
+    {
+        const unsigned r = (unsigned)wm * 32u + (unsigned)l31, sw = (r >> 1) & 7u;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) fa_off[ks][h] = r * 128u + ((((unsigned)(4 * ks + 2 * hi + h)) ^ sw) * 16u);
+            f_off[ks] = (unsigned)A_BYTES + ((unsigned)wn * 32u + (unsigned)l31) * XROW + ((((unsigned)(2 * ks + hi)) ^ (((unsigned)l31 >> 2) & 3u)) * 16u);
+        }
+    }
+    floatx16 acc, acc_lo;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc[r] = 0.f; acc_lo[r] = 0.f; }
+
+#pragma unroll
+    for (int d = 0; d < PD; d++) dma(d < nk ? d : nk - 1, (unsigned)d);
+    for (int kt = 0; kt < nk; kt++) {
+        // tile kt has landed (this wave's share: tiles kt + 1, kt + 2 are the younger ones in flight), then everybody's; the barrier also says
+        // every wave is done with tile kt - 1, whose slot the next DMA refills
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((PD - 1) * N_TILE) : "memory");
+        { const int kn = kt + PD; dma(kn < nk ? kn : nk - 1, (unsigned)(kn & (SLOTS - 1))); }      // (past the end: a harmless re-read keeps the count constant)
+        const unsigned char* S = &sm[(kt & (SLOTS - 1)) * SLOT_BYTES];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const float4 r0 = *(const float4*)(S + fa_off[ks][0]), r1 = *(const float4*)(S + fa_off[ks][1]);
+            unsigned pl[3][4];
+            if constexpr (FMT == 1) {
+                x3_split2_f16(r0.x, r0.y, pl[0][0], pl[1][0]); x3_split2_f16(r0.z, r0.w, pl[0][1], pl[1][1]);
+                x3_split2_f16(r1.x, r1.y, pl[0][2], pl[1][2]); x3_split2_f16(r1.z, r1.w, pl[0][3], pl[1][3]);
+            } else {
+                x3_split2(r0.x, r0.y, pl[0][0], pl[1][0], pl[2][0]); x3_split2(r0.z, r0.w, pl[0][1], pl[1][1], pl[2][1]);
+                x3_split2(r1.x, r1.y, pl[0][2], pl[1][2], pl[2][2]); x3_split2(r1.z, r1.w, pl[0][3], pl[1][3], pl[2][3]);
+            }
+            bf16x8 fa[NP], fb[NP];
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                fa[p] = __builtin_bit_cast(bf16x8, make_uint4(pl[p][0], pl[p][1], pl[p][2], pl[p][3]));
+                fb[p] = __builtin_bit_cast(bf16x8, *(const uint4*)(S + p * BN * XROW + f_off[ks]));
+            }
+            if constexpr (FMT == 1) {
+                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, fa[1]), __builtin_bit_cast(x3_f16x8, fb[0]), acc_lo, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, fa[0]), __builtin_bit_cast(x3_f16x8, fb[0]), acc, 0, 0, 0);
+                acc_lo = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(x3_f16x8, fa[0]), __builtin_bit_cast(x3_f16x8, fb[1]), acc_lo, 0, 0, 0);
+            } else {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], acc, 0, 0, 0);       // six terms, smallest first (as k_gemm_x3)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], acc, 0, 0, 0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");       // the re-reads past the end have landed before the ring is reused or released
+
+    if constexpr (FMT == 1) {                              // f16 pair: fold the scaled low terms in
+        float chk = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc[r] += acc_lo[r] * (1.0f / X3_F16_SCALE); chk = fmaf(acc[r], 0.f, chk); }
+        x3_report_range(g.status, chk);
+    }
+    // ---- epilogue (C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)), as k_gemm_x3
+    {
+        const int col = n0 + wn * 32 + l31;
+        const int rbase = m0 + wm * 32 + 4 * hi;
+        if (g.partial) {   // split-K: raw accumulators, epilogue happens in k_x3_splitk_reduce[_stats]
+            float* P = g.partial + (size_t)blockIdx.z * g.M * g.N;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < g.M) P[(size_t)row * g.N + col] = acc[r];
+            }
+        } else {
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            float rd[16], rs[16];
+            if (g.row_div) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) rd[r] = g.row_div[min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1)];
+            }
+            if (g.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) rs[r] = g.residual[(size_t)min(rbase + (r & 3) + 8 * (r >> 2), g.M - 1) * g.ldr + col];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                float v = acc[r];
+                if (g.row_div) v = v / rd[r];
+                v += bv;
+                if (g.act == 1) v = fmaxf(v, 0.f);
+                if (g.residual) v += rs[r];
+                if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+                acc[r] = v;
+            }
+        }
+    }
+    if constexpr (SOUT) {       // per (tile, cloud) column sums of the finished values (float64, fixed order), as k_gemm_x3
+        double2* red = (double2*)&sm[0];                   // [2 row blocks][BN]
+        for (int sg = s_lo; sg <= s_hi; sg++) {            // workgroup-uniform; one cloud per tile almost always
+            const int r_lo = sg == s_lo ? s_lo_begin : g.stat_seg_off[sg];
+            const int r_hi = min(sg == s_lo ? s_lo_end : g.stat_seg_off[sg + 1], g.M);
+            double sm_ = 0.0, sq = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + wm * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                if (row >= r_lo && row < r_hi) { const double v = (double)acc[r]; sm_ += v; sq += v * v; }
+            }
+            sm_ += __shfl_xor(sm_, 32, RG_WAVE); sq += __shfl_xor(sq, 32, RG_WAVE);
+            if (hi == 0) red[wm * BN + wn * 32 + l31] = make_double2(sm_, sq);
+            __syncthreads();
+            if (t < BN) {
+                double2 a = red[t];
+                const double2 b = red[BN + t];
+                a.x += b.x; a.y += b.y;
+                g.stat_partial[(size_t)(tile_m + sg) * g.N + n0 + t] = a;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // (Round 4 built an A-RESIDENT strip kernel for the short-K products -- A fragments kept in registers for a whole range of columns, weight
 //  planes through an eight-slot LDS ring, one wave per SIMD -- and removed it after measurement: 107-163 us against 92-127 us for k_gemm_x3d on
 //  the K = 256 cross-encoder shapes; phase clocks and the reading in profiles/r04_gemm_ares.md.)
@@ -1423,6 +1615,7 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
         else k_gemm_x3d<MW_, CW_, AR_, false><<<grid, 64 * MW_, 0, st>>>(g); } while (0)
     const bool strip = p.strip && !a_stats && K % XBK == 0 && p.k_chunk % XBK == 0;
     static const int a_ring = X3_DEV_ENV("REGTR_X3_ARING", 3);   // development: A/B runs
+    static const int deep_pipe = X3_DEV_ENV("REGTR_X3_DEEP", 1);   // development: A/B runs
     // (measured and left out: 8 waves on 256 x 128 tiles, 144 KiB of LDS, one workgroup per CU -- k_gemm_x3d<8, 4, 3> -- halves the
     // weight traffic per MFMA and is no faster: 498 vs 483 us on the level-2 contraction, 555 vs 478 at level 3 where 296 tiles
     // quantise badly over 256 CUs)
@@ -1436,6 +1629,12 @@ int regtr_gemm_x3(const float* A, int lda, const void* planes, float* C, int ldc
     else if (strip && p.tile == 0) X3D_LAUNCH(4, 4, 2);              // 128 x 128: 4 waves of 32 rows x 128 columns, both operands by LDS-DMA
     else if (strip && a_ring == 3) X3D_LAUNCH(4, 2, 3);              // 128 x 64, A rows two tiles ahead
     else if (strip) X3D_LAUNCH(4, 2, 2);                             // 128 x 64
+    // small problems on 64 x 64 tiles (at most two workgroups per CU, no folded operand): the three-deep operand pipeline (k_gemm_x3q)
+    else if (deep_pipe && p.tile == 2 && !a_stats && (n_planes == 3 || n_planes == 4) && K % XBK == 0 && p.k_chunk % XBK == 0 &&
+             (long long)rg_cdiv(M, 64) * (N / 64) * p.splits <= 512) {
+        if (n_planes == 4) { if (stat_partial) k_gemm_x3q<true, 2, 1><<<grid, 256, 0, st>>>(g); else k_gemm_x3q<false, 2, 1><<<grid, 256, 0, st>>>(g); }
+        else { if (stat_partial) k_gemm_x3q<true, 3, 0><<<grid, 256, 0, st>>>(g); else k_gemm_x3q<false, 3, 0><<<grid, 256, 0, st>>>(g); }
+    }
     else if (p.tile == 0) X3_LAUNCH(2, 4, 2, 1);     // 128 x 128, 8 waves of 64 x 32
     else if (p.tile == 1) X3_LAUNCH(2, 2, 2, 1);     // 128 x 64, 4 waves of 64 x 32
     else X3_LAUNCH(2, 2, 1, 1);                      // 64 x 64, 4 waves of 32 x 32
