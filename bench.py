@@ -118,12 +118,19 @@ def measure_gemm_roofline(model, batch, reps=3):
     during real forwards and prices each against BOTH rooflines: matrix pipe = 2 M N K x terms issued / 2.5 PFLOP/s (the f16 pair split
     issues 3 MFMA terms per product, bf16x3 six; the exact-f32 MFMA runs at 157.3 TFLOP/s) and HBM = (4 M K [x passes] + 4 M N +
     weight bytes) / 8 TB/s; a launch's bound is the larger of the two times.  -> the `roofline_gemm` block of the bench line."""
-    from regtr_amd import context
+    from regtr_amd import context, regtr as regtr_mod
     records = []
-    with context.recording(gemm_records=records):
-        for _ in range(reps):
-            model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
-        torch.cuda.synchronize()
+    # ONE stream while the launches are timed (round 5): with the pyramid on the second stream the level-0 products shared the chip with the
+    # radius kernels while their events ran, and their fractions were pessimistic by an unknown amount (VERDICT r04 weak #10)
+    two_streams = regtr_mod.overlap_preprocessing
+    regtr_mod.overlap_preprocessing = False
+    try:
+        with context.recording(gemm_records=records):
+            for _ in range(reps):
+                model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
+            torch.cuda.synchronize()
+    finally:
+        regtr_mod.overlap_preprocessing = two_streams
     shapes = {}
     for e0, e1, m in records:
         key = (m['route'], m['M'], m['N'], m['K'], m['fold'], m['stats'])
@@ -148,7 +155,7 @@ def measure_gemm_roofline(model, batch, reps=3):
                      'TFLOPs_f32_equiv': round(flops / t / 1e12, 1), 'GBs': round(bytes_ / t / 1e9)})
     rows.sort(key=lambda r: -r['us'] * r['launches_per_step'])
     return {'what': 'every dense contraction of a forward (KPConv kernel-point contractions, unary / shortcut / projection / FFN / head Linears), '
-                    'event-timed per launch; frac = roofline time (the larger of matrix-pipe and HBM time) / measured time',
+                    'event-timed per launch with the forward on ONE stream (nothing else on the chip while a launch is timed); frac = roofline time (the larger of matrix-pipe and HBM time) / measured time',
             'ms_per_step': round(tot * 1e3, 3), 'roofline_ms_per_step': round(tot_bound * 1e3, 3), 'frac': round(tot_bound / tot, 3),
             'launches_per_step': sum(r['launches_per_step'] for r in rows),
             'by_route_ms': {k: round(v[0] * 1e3, 3) for k, v in sorted(by_route.items(), key=lambda kv: -kv[1][0])},
