@@ -10,7 +10,7 @@ import os
 
 import torch
 
-from . import _lib, ops
+from . import ops
 from ._lib import _F, _I, _P, _Z, bptr, check, iptr, ptr, raw, stream
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libregtr_hip.experimental.so')
