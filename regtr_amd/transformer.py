@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, context, ops
-from .kpconv import _prepared
+from .kpconv import _prepared, param_fingerprint
 
 
 class TransformerCrossEncoderLayer(nn.Module):
@@ -152,12 +152,8 @@ class TransformerCrossEncoder(nn.Module):
                     and ops.f16_pair_ok(n, F, D) and ops.f16_pair_ok(n, D, F))
 
     def _fingerprint(self):
-        """Cheap identity of everything the cached tables point at: (storage address, version) of every parameter -- ~100 attribute reads,
-        against rebuilding 108 pointers through the weight caches (0.2 ms of a 2.5 ms one-pair forward, tools/host_profile.py)."""
-        fp = []
-        for prm in self.parameters():
-            fp.append(prm.data_ptr()); fp.append(prm._version)
-        return tuple(fp)
+        """Cheap identity of everything the cached tables point at (kpconv.param_fingerprint)."""
+        return param_fingerprint(self)
 
     def _param_table(self, f16=False):
         """(ctypes array of the layers' device pointers in regtr_cross_encoder_fwd's order, ctypes array of the norm eps) -- rebuilt only
