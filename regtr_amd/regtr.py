@@ -41,7 +41,6 @@ class PositionEmbeddingCoordsSine(nn.Module):
 # A-B switch and size gate of the two-stream forward (RegTR._forward)
 overlap_preprocessing = devflags.on('REGTR_OVERLAP')          # (read only under REGTR_DEV=1)
 OVERLAP_MIN_POINTS = 131072
-EARLY_LEVEL0 = devflags.on('REGTR_EARLY_L0')       # small batches: the level-0 blocks enqueued behind the pyramid before the host waits for the level sizes
 
 
 class CorrespondenceRegressor(nn.Module):
@@ -284,20 +283,6 @@ class RegTR(nn.Module):
                 kpconv_meta = self.preprocessor(clouds)          # blocks already enqueued read level 0 only, which is never truncated
             else:
                 self._record_meta(kpconv_meta, main)
-            batch['kpconv_meta'] = kpconv_meta
-            feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
-        elif (EARLY_LEVEL0 and n_l0 > 0 and not ev and n0 < ops.SMALL_REGIME_ROWS and ops.use_one_call_encoder
-              and not self.cfg.get('kpconv_ref_row_order', False)):
-            # A pair or two per forward, ONE stream: the level-0 blocks need no level size from the device (theirs are the inputs' own), so
-            # they are enqueued BEHIND the pyramid before the host waits for the sizes -- the GPU then has 0.25 ms of work in its queue while
-            # the host wakes up from that wait, builds kpconv_meta and prepares the rest of the encoder (the same launches in the same
-            # order on the same stream: nothing about the GPU's schedule changes, only when the host issues it).
-            state = self.preprocessor.enqueue(clouds)
-            meta0 = self.preprocessor.level0_meta(state)
-            x, skips = self.kpf_encoder(self._ones(n0, dev), meta0, 0, n_l0)
-            kpconv_meta = self.preprocessor.finish(state)
-            if kpconv_meta is None:      # a level filled a (forced) capacity: the pyramid once more at full capacity; level 0 is never truncated
-                kpconv_meta = self.preprocessor(clouds)
             batch['kpconv_meta'] = kpconv_meta
             feats_un, _ = self.kpf_encoder(x, kpconv_meta, n_l0, None, skips)
         else:
