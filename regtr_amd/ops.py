@@ -406,7 +406,7 @@ def kpconv_norm_lrelu(q_xyz, s_xyz, nbr, x, w16_kn, kernel_points, extent, seg_o
 STREAM_MIN_ROWS = 131072     # below this a forward is launch-bound (a pair or two): the tiled kernels and separate passes are as fast
 # The SMALL-batch regime: forwards with fewer level-0 rows than this take the small-batch kernel forms at EVERY level (no packed support
 # records / pre-normalised gather, no strip GEMM, no block tails) and the encoder's blocks go out through one C call (regtr_encoder_fwd).
-# Measured with the one-call encoder (gpurun_out/r05_h: bench.py --pairs n, small regime forced on / off): 2 pairs 3.01 vs 3.30 ms, 3 pairs
+# Measured with the one-call encoder (profiles/r05_ab_h.txt: bench.py --pairs n, small regime forced on / off): 2 pairs 3.01 vs 3.30 ms, 3 pairs
 # 3.32 vs 3.50, 4 pairs 3.85 vs 3.67, 8 pairs 5.52 vs 5.33 -- the crossover sits between 114 k and 152 k rows.  (Round 4, op-by-op issue: 65536.)
 SMALL_REGIME_ROWS = int(devflags.flag('REGTR_SMALL_ROWS', '131072'))
 use_stream_gemm = devflags.on('REGTR_STREAM_GEMM')      # one-shot strip kernel for the shallow levels' Linears
