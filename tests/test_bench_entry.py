@@ -95,3 +95,25 @@ def test_parity_check_logic_on_cpu():
     bad['tgt_kp'][0][3, 1] += 1e-6
     r = bench.parity_check(cfg, Model(), pairs, bad, [0, 1])
     assert not r['ok'] and not r['keypoints_bit_exact']
+
+
+def test_real_pairs_workload_is_deterministic_and_rigid():
+    """bench.real_pairs (`bench.py --real`): the three shipped 3DMatch pairs (tests/golden fixtures) replicated under random rigid motions --
+    slots 0-2 are the originals bit for bit, every replica is a float32 rigid image of its original (pairwise distances preserved to float32
+    rounding), replicas differ from each other, and the workload is a function of the slot ids alone."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    a, b = bench.real_pairs(7), bench.real_pairs(7)
+    for (s1, t1), (s2, t2) in zip(a, b):
+        assert np.array_equal(s1, s2) and np.array_equal(t1, t2) and s1.dtype == np.float32
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', '3dmatch_kitchen.npz'))
+    assert np.array_equal(a[0][0], g['src']) and np.array_equal(a[0][1], g['tgt'])
+    assert [len(s) for s, _ in a[:3]] == [len(s) for s, _ in a[3:6]] and not np.array_equal(a[0][0], a[3][0]) and not np.array_equal(a[3][0], a[6][0])
+    rng = np.random.default_rng(0)
+    i, j = rng.integers(0, len(a[0][0]), 200), rng.integers(0, len(a[0][0]), 200)
+    d0 = np.linalg.norm(a[0][0][i].astype(np.float64) - a[0][0][j], axis=1)
+    d3 = np.linalg.norm(a[3][0][i].astype(np.float64) - a[3][0][j], axis=1)
+    assert np.abs(d0 - d3).max() < 5e-6                      # rigid: distances survive (float32 rounding of ~4 m coordinates)
+    assert bench.real_pairs(2, first_id=3)[0][0].tobytes() == a[3][0].tobytes()
