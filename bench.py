@@ -270,7 +270,7 @@ def collect_pmc(args):
         sys.exit('bench.py --collect-pmc: no KPConv gather launch in the counter output')
     total = sum(v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) for v in g.values())
     code = code_version()
-    pairs = args.pairs if args.pairs else 64
+    pairs = args.pairs if args.pairs else DEFAULT_PAIRS['3dmatch']
     res = {'workload': {'pairs': pairs, 'points': args.points, 'shuffle': bool(args.shuffle)}, 'hbm_bytes_per_launch': total / n, 'code': code,
            'source': ('`python bench.py --collect-pmc`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over '
                       f'`bench.py --steps 2 --warmup 1`; bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE KB; mean '
@@ -383,6 +383,12 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0, cfg_name='3dmatch'):
                       f'median s/pair {med:.3f}{split}'}
 
 
+# pairs per forward when --pairs is not given.  3dmatch: 192 since round 5 -- the same kernels, 2.8-3.8 % more pairs/s than 64 per forward on one
+# box (64 / 96 / 128 / 192: 2366 / 2433 / 2410-2423 / 2455 pairs/s, profiles/r05_z_batch_sweep.txt; 20.8 GiB of the 288 GB): a forward's fixed costs
+# -- host set-up, the two host reads, the last partial round of every launch's workgroups -- are spread over three times the pairs.  lomatch keeps
+# 64 per forward (ragged 223-pair shards), modelnet 256.
+DEFAULT_PAIRS = {'3dmatch': 192, 'modelnet': 256, 'lomatch': 64}
+
 REAL_PAIRS = ('3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at')     # tests/golden/*.npz: the clouds of /root/reference/src/demo.py:26-49 examples 0-2
 
 
@@ -391,7 +397,7 @@ def real_pairs(n_pairs, first_id=0):
     lattice ties, home_at with 22.7 % of its level-0 balls over K = 40; the clouds travel as the committed fixtures tests/golden/3dmatch_*.npz)
     replicated to `n_pairs`: slots 0-2 are the originals, every further slot is pair (slot % 3) with each cloud under its own random rigid motion
     (rotation <= 45 deg about a random axis, |t| <= 0.5 m: conf/3dmatch.yaml's augmentation ranges), seeded by the slot id, applied in float32
-    -- 64 different inputs with real-scan neighbourhood statistics.  -> [(src, tgt) float32 numpy]"""
+    -- `n_pairs` different inputs with real-scan neighbourhood statistics.  -> [(src, tgt) float32 numpy]"""
     from regtr_amd.synthetic import random_se3
     base = [np.load(os.path.join(ROOT, 'tests', 'golden', f'{n}.npz')) for n in REAL_PAIRS]
     base = [(np.ascontiguousarray(g['src'], np.float32), np.ascontiguousarray(g['tgt'], np.float32)) for g in base]
@@ -578,7 +584,7 @@ def plan_pairs(args, rank, world, device):
     -> (lomatch, per_fwd, pair_ids (n_local,) i32 on `device`, chunks [(lo, hi)], pairs_per_step over all ranks)"""
     from regtr_amd.distributed import shard_pairs
     lomatch = args.config == 'lomatch'
-    per_fwd = args.pairs if args.pairs else (256 if args.config == 'modelnet' else 64)
+    per_fwd = args.pairs if args.pairs else DEFAULT_PAIRS[args.config]
     args.pairs = per_fwd
     if lomatch:
         mine = shard_pairs(args.total_pairs, rank, world)
@@ -665,7 +671,7 @@ def main():
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
     ap.add_argument('--parity-pairs', type=int, default=8, help='pairs of the last timed step checked against the CPU oracle: first, last, largest, smallest slot of the batch + evenly spaced others (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
-    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 64 for 3dmatch, 256 for modelnet; pairs are independent, 288 GB of HBM holds far more)')
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 192 for 3dmatch, 256 for modelnet, 64 per forward for lomatch; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--real', action='store_true', help='3dmatch: the three REAL pairs the reference ships (demo.py:26-49; tests/golden fixtures) replicated to --pairs under random rigid motions, instead of synthetic rooms')
