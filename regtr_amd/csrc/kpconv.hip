@@ -872,7 +872,10 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
 // row load sits in its own predicated block, so the "8 rows in flight" never were: one dependent round trip after the other (index,
 // row, index, row ...).  Here the index row is read with clamped column numbers (a repeated neighbour does not change a maximum), the
 // feature rows with range-checked buffer loads (an offset of RG_OOB returns zeros: exactly the zero shadow row), HB rows per batch
-// all issued before the first maximum.  Needs ns * C * 4 < 2^31 (buffer offsets).
+// all issued before the first maximum.  Needs ns * C * 4 < 2^32 - 256 (32-bit unsigned buffer offsets; MP_OOB, not RG_OOB, is the out-of-range
+// offset here: the level-0 rows of a 192-pair forward are 3.7 GB, and with RG_OOB's 2 GiB bound that launch fell back to the predicated kernel
+// above -- 2.65 ms against 1.9 for three times the 64-pair launch).
+constexpr unsigned MP_OOB = 0xfffffff0u;
 template <int QW, int HB>
 __global__ void __launch_bounds__(256) k_maxpool_gather_buf(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
                                                             int ld_nbr, int nq, int H, float* __restrict__ out)
@@ -893,7 +896,7 @@ __global__ void __launch_bounds__(256) k_maxpool_gather_buf(const float* __restr
             for (int u = 0; u < HB; u++) idx[u] = row[min(h0 + u, H - 1)];
             float4 v[HB];
 #pragma unroll
-            for (int u = 0; u < HB; u++) v[u] = rg_buf_load<4>(x_rs, (unsigned)idx[u] < (unsigned)ns ? (unsigned)idx[u] * row_bytes + cb : RG_OOB);
+            for (int u = 0; u < HB; u++) v[u] = rg_buf_load<4>(x_rs, (unsigned)idx[u] < (unsigned)ns ? (unsigned)idx[u] * row_bytes + cb : MP_OOB);
 #pragma unroll
             for (int u = 0; u < HB; u++) {
                 m.x = fmaxf(m.x, v[u].x); m.y = fmaxf(m.y, v[u].y); m.z = fmaxf(m.z, v[u].z); m.w = fmaxf(m.w, v[u].w);
@@ -1024,7 +1027,7 @@ int regtr_maxpool_gather(const float* x, int ns, int C, const int* nbr, int ld_n
 {
     if (!x || !nbr || !out || ns < 0 || nq < 0 || H < 1 || ld_nbr < H || C < 4 || C % 4) return RG_ERR_ARG;
     if (nq == 0) return RG_OK;
-    if (ns > 0 && (unsigned long long)ns * C * 4ull < 0x80000000ull && ((uintptr_t)x % 16) == 0) {      // the branch-free form (buffer offsets < 2 GiB)
+    if (ns > 0 && (unsigned long long)ns * C * 4ull < 0xffffff00ull && ((uintptr_t)x % 16) == 0) {      // the branch-free form (32-bit buffer offsets)
         if (C <= 64) k_maxpool_gather_buf<4, 8><<<rg_xcd_grid(rg_cdiv(nq, 16)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
         else if (C <= 128) k_maxpool_gather_buf<2, 8><<<rg_xcd_grid(rg_cdiv(nq, 8)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);
         else k_maxpool_gather_buf<1, 8><<<rg_xcd_grid(rg_cdiv(nq, 4)), 256, 0, (hipStream_t)stream>>>(x, ns, C, nbr, ld_nbr, nq, H, out);

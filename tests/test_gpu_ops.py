@@ -498,6 +498,26 @@ def test_maxpool_instnorm_vs_oracle():
         assert (out2 - ref2).abs().max() < 4e-5
 
 
+def test_maxpool_rows_beyond_2_gib():
+    """Level 0 of a 192-pair forward (bench.py's default since round 5) hands regtr_maxpool_gather 3.7 GB of feature rows: the branch-free kernel's
+    buffer offsets are 32-bit UNSIGNED and its out-of-range offset sits above 4 GiB - 256, so rows between 2 and 4 GiB must be gathered like
+    any other (max over the listed rows, a zero row for the shadow index ns; kpconv_blocks.py:127-143) -- checked on 4096 queries whose
+    neighbours are spread over the whole table, the shadow index included."""
+    ops = _ops()
+    ns, C, H, nq = 6_000_000, 128, 40, 4096          # 3.07 GB of rows
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn((ns, C), device='cuda', generator=g)
+    idx = torch.randint(0, ns + 1, (nq, H), device='cuda', generator=g, dtype=torch.int64)
+    idx[:, -3:] = ns                                   # shadow neighbours
+    idx[0, :] = ns - 1                                 # the last row of the table: offset 3.07 GB
+    idx[1, :] = ns                                     # only shadows: zeros
+    out = ops.maxpool(x, idx.to(torch.int32))
+    xp = torch.cat([x, torch.zeros((1, C), device='cuda')])
+    ref = torch.stack([xp[idx[i0:i0 + 256]].amax(1) for i0 in range(0, nq, 256)]).reshape(nq, C)
+    assert torch.equal(out, ref)
+    assert float(out[1].abs().max()) == 0.0 and torch.equal(out[0], x[ns - 1])
+
+
 # ------------------------------------------------------------------------------------------------ transformer kernels
 def test_layernorm_posemb_vs_oracle():
     from oracle import regtr_ref
