@@ -603,8 +603,14 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     from regtr_amd.distributed import gather_poses
     n_set = args.total_pairs if lomatch else int(pair_ids.numel()) * (dist.get_world_size() if dist else 1)      # (weak scaling: every rank holds the same count)
     gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids, n_set)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
+    warm = None
     for _ in range(args.warmup):
-        step()
+        warm, _ = step()
+    if dist and warm is not None:
+        # a warm-up pass ends like a timed one, with the pose gather: the FIRST all_gather_into_tensor of a process builds RCCL's channels and
+        # loads its kernels -- ~80 ms measured at world 1 (tools/torchrun_ab.sh: 87.7 vs 78.0 ms per step over 8 steps), which a plain
+        # `python bench.py` (no process group) never pays and a torchrun launch would otherwise pay inside the timed region
+        gather(warm)
     sync()
     if dist: dist.barrier()
     t0 = time.perf_counter()

@@ -190,7 +190,13 @@ class RegTR(nn.Module):
         return ent[:n]
 
     def _side_stream(self, dev):
-        return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias, lambda _: torch.cuda.Stream(device=dev))
+        """The pyramid's stream (large batches: levels 1-3 are built under the level-0 blocks).  HIGH priority, not for the priority: HIP maps
+        the streams of one priority onto a small pool of hardware queues, and a stream that lands on the main stream's queue is serialised
+        behind it.  That happened as soon as the process also held an RCCL communicator (its streams shift the mapping): a 192-pair forward
+        79.98 ms under a world-1 process group against 77.84 ms without, the rocprofv3 trace showing no overlap at all (busy 78.2 ms inside 79.5 ms
+        of wall time, against 84.4 inside 76.6).  A high-priority stream draws from its own queue pool: 78.20 / 77.94 ms (profiles/r05_z_dist_stream.txt)."""
+        return _prepared(self._cache, ('side_stream', dev), self.feat_proj.bias,
+                         lambda _: torch.cuda.Stream(device=dev, priority=int(devflags.flag('REGTR_SIDE_PRIO', '-1'))))
 
     @staticmethod
     def _record_meta(meta, stream):
