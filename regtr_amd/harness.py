@@ -227,7 +227,7 @@ class Prefetcher:
     def __init__(self, pairs, indices, batch, device, depth=2):
         self.pairs, self.indices, self.batch, self.device = pairs, list(indices), batch, device
         self.q = queue.Queue(maxsize=depth)
-        self.copy_stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
+        self.copy_stream = torch.cuda.Stream(device=device, priority=-1) if device.type == 'cuda' else None      # (own hardware-queue pool, see LoaderPool.iterate)
         self.thread = threading.Thread(target=self._work, daemon=True)
         self.thread.start()
 
@@ -379,7 +379,9 @@ class LoaderPool:
         for sid in range(len(self.slabs)):
             free.put(sid)
         if self.cuda and self.copy_stream is None:
-            self.copy_stream = torch.cuda.Stream(device=self.device)
+            # high priority = a hardware queue from another pool than the forward's stream (regtr.py: _side_stream; an RCCL communicator in
+            # the process had put a normal-priority side stream onto the main stream's queue, i.e. behind the forward it should run next to)
+            self.copy_stream = torch.cuda.Stream(device=self.device, priority=-1)
         if self._source_file is None:
             raise RuntimeError('LoaderPool.iterate: no pair source (set_source)')
         import sys
