@@ -597,19 +597,20 @@ def plan_pairs(args, rank, world, device):
     return lomatch, per_fwd, pair_ids, chunks, (args.total_pairs if lomatch else per_fwd * world)
 
 
-def settle_device(step, budget_s):
+def settle_device(step, budget_s, sync=None):
     """Set-up, before the W warm-up steps: `budget_s` seconds of untimed passes, so that the device is at its sustained state when the warm-up
     starts.  Why: on 3 of ~15 fresh boxes the FIRST seconds of sustained GPU work ran 20-45 % slow -- the default line's 20 timed steps 95.7 ms
     each while every side measurement taken a few seconds later in the same process (gather, GEMM and pyramid event timings, the fp32x3 forwards)
     was within 4 % of a normal box; two consecutive processes slow, the following ones not (profiles/r05_z_dist_stream.txt) -- whatever the
     code version and launch mode.  A plateau of slow passes looks steady, so the phase has a fixed length instead of a convergence test;
     `config.settle` reports the first and last pass times.  -> {'passes', 'seconds', 'first_ms', 'last_ms'}"""
+    sync = sync or torch.cuda.synchronize
     ts = []
     t_begin = time.perf_counter()
     while time.perf_counter() - t_begin < budget_s:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sync(); t0 = time.perf_counter()
         step()
-        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        sync(); ts.append((time.perf_counter() - t0) * 1e3)
     return {'passes': len(ts), 'seconds': round(time.perf_counter() - t_begin, 2), 'first_ms': [round(t, 2) for t in ts[:3]], 'last_ms': [round(t, 2) for t in ts[-3:]]}
 
 

@@ -117,3 +117,16 @@ def test_real_pairs_workload_is_deterministic_and_rigid():
     d3 = np.linalg.norm(a[3][0][i].astype(np.float64) - a[3][0][j], axis=1)
     assert np.abs(d0 - d3).max() < 5e-6                      # rigid: distances survive (float32 rounding of ~4 m coordinates)
     assert bench.real_pairs(2, first_id=3)[0][0].tobytes() == a[3][0].tobytes()
+
+
+def test_settle_phase_has_a_fixed_length_and_reports_its_passes():
+    """bench.settle_device: untimed set-up passes for a fixed number of seconds before the warm-up steps (a slow plateau must not end it early),
+    nothing when the budget is 0; and the defaults the driver's flag-less run gets."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+    r = bench.settle_device(lambda: (calls.append(1), time.sleep(0.01)), 0.15, sync=lambda: None)
+    assert r['passes'] == len(calls) >= 5 and 0.15 <= r['seconds'] < 1.0 and len(r['first_ms']) == 3 and all(t >= 9.0 for t in r['last_ms'])
+    assert bench.settle_device(lambda: calls.append(1), 0.0, sync=lambda: None)['passes'] == 0
+    assert bench.DEFAULT_PAIRS == {'3dmatch': 192, 'modelnet': 256, 'lomatch': 64} and bench.REDUCED_TOL['pose'] <= 0.1
