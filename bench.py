@@ -35,14 +35,11 @@ MFMA_BF16_PEAK_TFS = 2500.0   # dense bf16 MFMA peak (same guide); the f32-input
 
 
 from regtr_amd.synthetic import synth_modelnet_pair, synth_pair  # noqa: E402  
+from regtr_amd.workload import (DEFAULT_PAIRS, REAL_PAIRS, REDUCED_TOL, build_workload, kpconv_algorithmic_bytes, parity_slots,  # noqa: E402,F401
+                                probe_head, real_pairs)
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
-    """B_kp = Nq*H*(4 + 12 + 4*Cin) + Nq*(12 + 4*Cout) + 15*Cin*Cout*4 (fp32 feats, int32 idx)."""
-    return nq * H * (4 + 12 + 4 * cin) + nq * (12 + 4 * cout) + kp * cin * cout * 4
-
-
 class one_stream:
     """`with one_stream():` -- the forwards inside run on ONE stream (RegTR's second, pyramid stream off).  The per-launch event timings of the
     roofline blocks are taken this way since round 5: with the pyramid next to them a level-0 launch shared the chip with the radius kernels while
@@ -58,7 +55,7 @@ class one_stream:
         return False
 
 
-def measure_kpconv_roofline(model, batch, reps=5):
+def measure_kpconv_roofline(model, batch, reps=5, keep=None):
     """Times every KPConv gather launch (k_kpconv_gather_*) with HIP events on the stream it is enqueued on (torch's current stream) during
     real forwards run on one stream; achieved = sum of algorithmic bytes / sum of durations."""
     from regtr_amd import context
@@ -67,6 +64,8 @@ def measure_kpconv_roofline(model, batch, reps=5):
         for _ in range(reps):
             model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
         torch.cuda.synchronize()
+    if keep is not None:
+        keep['gather'] = (records, reps)
     t_gather = sum(r[0].elapsed_time(r[1]) for r in records) * 1e-3
     t_gemm = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3
     alg = sum(kpconv_algorithmic_bytes(r[3], r[4], r[5], r[6]) for r in records)
@@ -129,7 +128,7 @@ def measure_attention(model, batch, n_heads, d_embed, n_layers, reps=5):
             'tokens_per_cloud_mean': float(np.mean(lens))}
 
 
-def measure_gemm_roofline(model, batch, reps=3):
+def measure_gemm_roofline(model, batch, reps=3, keep=None):
     """Times every dense launch (split GEMM in either format, one-shot strip, block tail, exact-f32) with HIP events on its stream
     during real forwards and prices each against BOTH rooflines: matrix pipe = 2 M N K x terms issued / 2.5 PFLOP/s (the f16 pair split
     issues 3 MFMA terms per product, bf16x3 six; the exact-f32 MFMA runs at 157.3 TFLOP/s) and HBM = (4 M K [x passes] + 4 M N +
@@ -142,6 +141,8 @@ def measure_gemm_roofline(model, batch, reps=3):
         for _ in range(reps):
             model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
         torch.cuda.synchronize()
+    if keep is not None:
+        keep['gemm'] = (records, reps)
     shapes = {}
     for e0, e1, m in records:
         key = (m['route'], m['M'], m['N'], m['K'], m['fold'], m['stats'])
@@ -224,6 +225,31 @@ def pmc_traffic(pairs, points, shuffle, detail, real=False):
     return t['hbm_bytes_per_launch']
 
 
+def forward_traffic(pairs, points, shuffle, real, compulsory_bytes):
+    """`forward_traffic` of the bench line: HBM bytes ONE forward moves (every kernel, from the stamped counter file of `--collect-pmc`) against
+    its compulsory bytes (regtr_amd/workload.py: forward_compulsory_bytes -- SURVEY.md Appendix B on this batch's level sizes) -- so that the
+    ratio (round 5: 260.7 GB against 23 GB, 12 x: the WF intermediate, the InstanceNorm passes, the split GEMMs' operands) is visible in every
+    line and cannot regress silently.  hbm_GB is null (with the reason) when the counter file is not of this workload and these kernel sources."""
+    out = {'hbm_GB': None, 'compulsory_GB': round(compulsory_bytes / 1e9, 3), 'ratio': None, 'top3': None,
+           'compulsory': 'every array of the path touched once: SURVEY.md Appendix B per KPConv block + preprocessing + tokens + weights, on this batch\'s level sizes'}
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+    except (OSError, ValueError):
+        out['note'] = 'profiles/pmc_traffic.json absent: run `python bench.py --collect-pmc` on the GPU'
+        return out
+    fw = t.get('forward')
+    if real or t.get('workload') != {'pairs': pairs, 'points': points, 'shuffle': bool(shuffle)} or not fw:
+        out['note'] = f"profiles/pmc_traffic.json was taken on another workload ({t.get('workload')})" if fw else 'profiles/pmc_traffic.json predates the per-forward totals'
+        return out
+    if t.get('code', {}).get('source_sha256') != code_version()['source_sha256']:
+        out['note'] = f"profiles/pmc_traffic.json was taken on other kernel sources (commit {t.get('code', {}).get('git_commit')}): re-run `python bench.py --collect-pmc`"
+        return out
+    out.update(hbm_GB=round(fw['hbm_bytes_per_forward'] / 1e9, 2), fetch_GB=round(fw['fetch_bytes_per_forward'] / 1e9, 2),
+               write_GB=round(fw['write_bytes_per_forward'] / 1e9, 2), ratio=round(fw['hbm_bytes_per_forward'] / compulsory_bytes, 2),
+               top3=fw['top3'], forwards_counted=fw['forwards'], source=t.get('source'), code=t.get('code'))
+    return out
+
+
 def collect_pmc(args):
     """`python bench.py --collect-pmc`: the counter passes behind `roofline.traffic`, reproducibly.  Two rocprofv3 runs (FETCH_SIZE, then
     WRITE_SIZE: separate passes, kernel trace only -- MI355X_MICROARCH.md's HBM recipe) over `bench.py --steps 2 --warmup 1` on the same
@@ -238,7 +264,7 @@ def collect_pmc(args):
     if not shutil.which('rocprofv3'):
         sys.exit('bench.py --collect-pmc: rocprofv3 not found')
     work = tempfile.mkdtemp(prefix='regtr_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
-    inner = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-roofline',
+    inner = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--settle-s', '0', '--no-cpu-baseline', '--no-roofline', '--no-real',
              '--parity-pairs', '0', '--no-strict-f32', '--points', str(args.points)] + (['--pairs', str(args.pairs)] if args.pairs else []) \
         + (['--shuffle'] if args.shuffle else [])
     vals = defaultdict(lambda: defaultdict(list))
@@ -264,6 +290,15 @@ def collect_pmc(args):
         f, w = v.get('FETCH_SIZE', []), v.get('WRITE_SIZE', [])
         kernels[k] = {'launches': max(len(f), len(w)), 'fetch_bytes_per_launch': 2 * 1024 * sum(f) / max(len(f), 1),
                       'write_bytes_per_launch': 1024 * sum(w) / max(len(w), 1)}
+    # per-forward totals over EVERY kernel: forwards = launches of the once-per-forward pose kernel
+    n_fwd = max(kernels.get('k_procrustes', {}).get('launches', 0), 1)
+    per_fwd = {k: v['launches'] * (v['fetch_bytes_per_launch'] + v['write_bytes_per_launch']) / n_fwd for k, v in kernels.items()}
+    forward = {'forwards': n_fwd,
+               'fetch_bytes_per_forward': sum(v['launches'] * v['fetch_bytes_per_launch'] for v in kernels.values()) / n_fwd,
+               'write_bytes_per_forward': sum(v['launches'] * v['write_bytes_per_launch'] for v in kernels.values()) / n_fwd,
+               'hbm_bytes_per_forward': sum(per_fwd.values()),
+               'top3': [{'kernel': k, 'GB': round(b / 1e9, 2), 'launches_per_forward': round(kernels[k]['launches'] / n_fwd, 1)}
+                        for k, b in sorted(per_fwd.items(), key=lambda kv: -kv[1])[:3]]}
     g = {k: v for k, v in kernels.items() if 'k_kpconv_gather' in k}
     n = sum(v['launches'] for v in g.values())
     if n == 0:
@@ -275,7 +310,7 @@ def collect_pmc(args):
            'source': ('`python bench.py --collect-pmc`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel trace only) over '
                       f'`bench.py --steps 2 --warmup 1`; bytes = 2 x FETCH_SIZE KB (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE KB; mean '
                       f'over {n} gather launches; kernel sources {code["source_sha256"][:12]}, commit {code["git_commit"]}'),
-           'gather_kernels': g}
+           'gather_kernels': g, 'forward': forward}
     os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
     with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w') as f:
         json.dump(res, f, indent=1)
@@ -284,7 +319,31 @@ def collect_pmc(args):
         f.write('| kernel | launches | fetch MB / launch | write MB / launch |\n|---|---|---|---|\n')
         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]['launches'] * (kv[1]['fetch_bytes_per_launch'] + kv[1]['write_bytes_per_launch'])):
             f.write(f"| {k} | {v['launches']} | {v['fetch_bytes_per_launch'] / 1e6:.1f} | {v['write_bytes_per_launch'] / 1e6:.1f} |\n")
-    print(json.dumps({k: res[k] for k in ('workload', 'hbm_bytes_per_launch', 'code')}))
+    print(json.dumps({k: res[k] for k in ('workload', 'hbm_bytes_per_launch', 'forward', 'code')}))
+
+
+def measure_real_fragments(args, dev, dtype, steps=8, parity_pairs=4):
+    """`real_fragments_pairs_per_s` of the default line: BASELINE configs[2] on the three REAL 3DMatch pairs the reference ships (demo.py:26-49; red-kitchen,
+    hotel_umd, home_at), replicated to the same pairs per forward under random rigid motions (workload.real_pairs), probe head -- 2 warm-up + `steps` timed
+    forwards between device synchronisations, then the CPU-oracle gate on `parity_pairs` of them."""
+    cfg_r, model_r, pairs_r, batch_r = build_workload('3dmatch', args.pairs, args.points, False, 0, dev, dtype, real=True)
+    for _ in range(2):
+        out = model_r(dict(batch_r))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model_r(dict(batch_r))
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    lv = [int(p.shape[0]) for p in model_r.preprocessor(list(batch_r['src_xyz']) + list(batch_r['tgt_xyz']))['points']]
+    info = {'value': args.pairs / dt, 'unit': 'pairs/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'pairs_per_step': args.pairs, 'level_points': lv,
+            'points_per_cloud': [int(np.mean([len(s) for s, _ in pairs_r])), int(np.mean([len(t) for _, t in pairs_r]))],
+            'data': 'the three 3DMatch pairs the reference ships (tests/golden/3dmatch_*.npz), replicated under random rigid motions; head: linear probe'}
+    if parity_pairs > 0:
+        slots = parity_slots([len(a) + len(b) for a, b in pairs_r], parity_pairs)
+        p = parity_check(cfg_r, model_r, pairs_r, out, slots)
+        info['parity'] = {k: p[k] for k in ('ok', 'pose_max_abs', 'corr_max_abs', 'kabsch_cond_max', 'pairs_checked', 'keypoints_bit_exact', 'reason')}
+    del model_r, batch_r
+    torch.cuda.empty_cache()
+    return info['value'], info
 
 
 def usable_cores():
@@ -383,114 +442,6 @@ def cpu_baseline(cfg, pairs, max_seconds=20.0, cfg_name='3dmatch'):
                       f'median s/pair {med:.3f}{split}'}
 
 
-# pairs per forward when --pairs is not given.  3dmatch: 192 since round 5 -- the same kernels, 2.8-3.8 % more pairs/s than 64 per forward on one
-# box (64 / 96 / 128 / 192: 2366 / 2433 / 2410-2423 / 2455 pairs/s, profiles/r05_z_batch_sweep.txt; 20.8 GiB of the 288 GB): a forward's fixed costs
-# -- host set-up, the two host reads, the last partial round of every launch's workgroups -- are spread over three times the pairs.  lomatch keeps
-# 64 per forward (ragged 223-pair shards), modelnet 256.
-DEFAULT_PAIRS = {'3dmatch': 192, 'modelnet': 256, 'lomatch': 64}
-REDUCED_TOL = {'correspondence': 2e-2, 'pose': 1e-1}      # gate of the bf16 / bf16x2 lines against the float32-grade run (see main)
-
-REAL_PAIRS = ('3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at')     # tests/golden/*.npz: the clouds of /root/reference/src/demo.py:26-49 examples 0-2
-
-
-def real_pairs(n_pairs, first_id=0):
-    """`--real`: the three REAL 3DMatch pairs the reference ships (demo.py:26-49: red-kitchen 0 / 5, hotel_umd 8 / 15, home_at 38 / 41 -- 6 mm
-    lattice ties, home_at with 22.7 % of its level-0 balls over K = 40; the clouds travel as the committed fixtures tests/golden/3dmatch_*.npz)
-    replicated to `n_pairs`: slots 0-2 are the originals, every further slot is pair (slot % 3) with each cloud under its own random rigid motion
-    (rotation <= 45 deg about a random axis, |t| <= 0.5 m: conf/3dmatch.yaml's augmentation ranges), seeded by the slot id, applied in float32
-    -- `n_pairs` different inputs with real-scan neighbourhood statistics.  -> [(src, tgt) float32 numpy]"""
-    from regtr_amd.synthetic import random_se3
-    base = [np.load(os.path.join(ROOT, 'tests', 'golden', f'{n}.npz')) for n in REAL_PAIRS]
-    base = [(np.ascontiguousarray(g['src'], np.float32), np.ascontiguousarray(g['tgt'], np.float32)) for g in base]
-    out = []
-    for i in range(n_pairs):
-        sl = first_id + i
-        s, t = base[sl % len(base)]
-        if sl >= len(base):
-            rng = np.random.default_rng(7000003 + sl)
-            (Rs, ts), (Rt, tt) = random_se3(rng, 45.0, 0.5), random_se3(rng, 45.0, 0.5)
-            s = (s @ Rs.astype(np.float32).T + ts.astype(np.float32)).astype(np.float32)
-            t = (t @ Rt.astype(np.float32).T + tt.astype(np.float32)).astype(np.float32)
-        out.append((s, t))
-    return out
-
-
-def probe_head(model, calib, dev, ridge=1.0):
-    """head_init 'probe': the output layer of the correspondence MLP (regtr.py:432-436, 3 x 256 + bias) fitted by ridge regression so that
-    the head predicts each token's OWN coordinates from the conditioned features of `calib` pairs (all six decoder layers, both clouds).
-    Why: the Kabsch covariance (se3_torch.py:108-154) is sum w (a - a_mean)(b - b_mean)^T over a = [src_kp ; tgt_corr], b = [src_corr ;
-    tgt_kp].  With a RANDOM output layer the predicted correspondences are spread over the object (singular values 6.7 / 5.0 / 3.4) but
-    UNCORRELATED with the key points (a linear fit explains 1.5 % of them): the covariance is a noise matrix, 0.020 / 0.011 / 0.0017, whose
-    condition number is an accident -- s1 / (s2 + s3) = 40 ... 380 on the ModelNet-size pairs, where the ORACLE's own float32 Kabsch is up to
-    1.1e-4 away from a float64 solve of the same inputs.  A trained head's predictions are a rigid image of the key points; the probe gives a
-    random-init network that property (r^2 ~ 0.3: the features carry the sine position embedding), the covariance becomes ~Var(kp), and
-    s1 / (s2 + s3) drops to 2 ... 11 on held-out pairs (float32-vs-float64 Kabsch 3e-7 ... 3e-6).  Everything upstream stays random-init."""
-    head = model.correspondence_decoder
-    with torch.no_grad():
-        out = model({'src_xyz': [torch.from_numpy(s).to(dev) for s, _ in calib], 'tgt_xyz': [torch.from_numpy(t).to(dev) for _, t in calib]})
-        H, T = [], []
-        for side in ('src', 'tgt'):
-            for f, kp in zip(out[side + '_feat'], out[side + '_kp']):           # f (6, N, D), kp (N, 3)
-                h = torch.relu(torch.nn.functional.linear(f.reshape(-1, f.shape[-1]), head.coor_mlp[0].weight, head.coor_mlp[0].bias))
-                h = torch.relu(torch.nn.functional.linear(h, head.coor_mlp[2].weight, head.coor_mlp[2].bias))
-                H.append(h.double()); T.append(kp.expand(f.shape[0], -1, -1).reshape(-1, 3).double())
-        X = torch.cat(H); X = torch.cat([X, torch.ones_like(X[:, :1])], 1)
-        T = torch.cat(T)
-        sol = torch.linalg.solve(X.T @ X + ridge * torch.eye(X.shape[1], dtype=X.dtype, device=X.device), X.T @ T)     # (D + 1, 3)
-        head.coor_mlp[4].weight.copy_(sol[:-1].T.float())
-        head.coor_mlp[4].bias.copy_(sol[-1].float())
-        r2 = 1.0 - float(((X @ sol - T) ** 2).sum() / ((T - T.mean(0)) ** 2).sum())
-    return r2
-
-
-def build_workload(config, n_pairs, points, shuffle, rank, dev, dtype, parity_mode=False, first_id=None, distinct=None, real=False,
-                   head_init=None):
-    """The benchmarked model and batch, exactly as the timed loop uses them (tests/test_gpu_bench_batch.py builds the same objects):
-    conf/<config>.yaml architecture with torch.manual_seed(0) random-init weights, `n_pairs` deterministic synthetic pairs
-    (ids rank * 100003 + i, or first_id + i) resident on `dev`.  config 'lomatch' = the 3dmatch pipeline on 10-30 %-overlap pairs.
-    real: the three shipped real 3DMatch pairs replicated under random rigid motions instead of synthetic rooms (real_pairs).
-    distinct: generate only that many different pairs and cycle through them (setup time; nothing is cached between pairs).
-    head_init: 'uniform' (synthetic 3DMatch-size default) or 'probe' (ModelNet-size and real-fragment default) -- see below / probe_head.
-    -> (cfg, model, pairs [(src, tgt) numpy], batch {'src_xyz': [...], 'tgt_xyz': [...]})"""
-    from regtr_amd import RegTR, load_config
-    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', f'{"3dmatch" if config == "lomatch" else config}.yaml'))
-    cfg.update({'compute_dtype': dtype})
-    if parity_mode:
-        cfg.update({'kpconv_ref_row_order': True})
-    torch.manual_seed(0); np.random.seed(0)
-    model = RegTR(cfg).to(dev).eval()
-    # The default nn.Linear init makes the head's last layer so small that every predicted correspondence collapses onto one point
-    # (spread 1.5 cm against 50 cm of key-point spread): the Kabsch covariance is then nearly rank one (s1 / (s2 + s3) 100 - 330 on
-    # these pairs) and R amplifies the last-bit differences between ANY two float32 implementations by that factor -- one pair in eight
-    # lands beyond 1e-4 on the pose with correspondences equal to 8e-7 (profiles/r04_a_bench_default_init.json).  "pose err vs ref" is
-    # meant to measure the kernels, so the benchmark draws that one 3 x 256 matrix from U(-0.5, 0.5) (as oracle/seeded_weights.py does
-    # for the goldens): predictions spread over metres, the Procrustes problem is well conditioned and the 1e-4 bar on R|t means what
-    # it says.  Still random-init weights; the throughput does not depend on their values.
-    # ModelNet-size pairs need more than spread (probe_head): there the output layer is a linear probe for the tokens' own coordinates.
-    head_init = head_init or ('probe' if (config == 'modelnet' or real) else 'uniform')      # (real fragments under the uniform layer: s1 / (s2 + s3) 30 - 60; probe: 1.5 - 5)
-    last = getattr(model.correspondence_decoder, 'coor_mlp', None)
-    with torch.no_grad():
-        if last is not None:
-            last[4].weight.uniform_(-0.5, 0.5)
-    if head_init == 'probe' and last is not None:
-        gen_c = synth_modelnet_pair if config == 'modelnet' else (lambda i: synth_pair(i, points, shuffle, overlap='lomatch' if config == 'lomatch' else None))
-        calib = real_pairs(4, 3) if real else [gen_c(900000 + i) for i in range(4)]       # calibration pairs: outside every benchmarked id range
-        model.head_probe_r2 = probe_head(model, calib, dev)
-    model.head_init = head_init
-    base = rank * 100003 if first_id is None else first_id
-    n_gen = n_pairs if not distinct else min(n_pairs, distinct)
-    if real:
-        gen = real_pairs(n_gen, base)
-    elif config == 'modelnet':
-        gen = [synth_modelnet_pair(base + i) for i in range(n_gen)]
-    else:
-        gen = [synth_pair(base + i, points, shuffle, overlap='lomatch' if config == 'lomatch' else None) for i in range(n_gen)]
-    pairs = [gen[i % n_gen] for i in range(n_pairs)]
-    dev_pairs = [(torch.from_numpy(s).to(dev), torch.from_numpy(t).to(dev)) for s, t in gen]
-    batch = {'src_xyz': [dev_pairs[i % n_gen][0] for i in range(n_pairs)], 'tgt_xyz': [dev_pairs[i % n_gen][1] for i in range(n_pairs)]}
-    return cfg, model, pairs, batch
-
-
 PARITY_TOL = 1e-4      # BASELINE.json north_star: "predicted correspondences and R|t within 1e-4 abs"
 
 
@@ -564,18 +515,6 @@ def parity_check(cfg, model, pairs, out, which, parity_mode=False):
                     ('reference row / tie orders (oracle/_ref), product in parity mode' if parity_mode else
                      'canonical tables from ' + ('the unmodified reference C++ neighbour sets (oracle/_ref)' if native.have_ref() else 'the C++ restatement'))),
                 what='outputs of the last timed step; random-init weights', seconds=round(time.perf_counter() - t0, 2))
-
-
-def parity_slots(sizes, n):
-    """Which slots of a forward's batch the parity check takes: the first and the last (packing offsets at both ends), the largest and
-    the smallest pair (by points), then evenly spaced others up to `n`."""
-    m = len(sizes)
-    want = [0, m - 1, int(np.argmax(sizes)), int(np.argmin(sizes))]
-    slots = []
-    for sl in want + [int(round(i * (m - 1) / max(n, 1))) for i in range(1, n + 1)] + list(range(m)):
-        if sl not in slots and len(slots) < min(n, m):
-            slots.append(sl)
-    return sorted(slots)
 
 
 def plan_pairs(args, rank, world, device):
@@ -702,6 +641,7 @@ def main():
     ap.add_argument('--head-init', choices=['uniform', 'probe'], default=None, help="output layer of the correspondence head: U(-0.5, 0.5) (3dmatch default) or a linear probe for the tokens' coordinates (modelnet default): bench.probe_head")
     ap.add_argument('--settle-s', type=float, default=5.0, help='set-up: seconds of untimed passes before the warm-up steps (the first seconds of sustained GPU work are slow on some boxes; 0 = off)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-real', action='store_true', help='skip the side measurement of the same configuration on the shipped real fragments (real_fragments_pairs_per_s)')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-strict-f32', action='store_true', help="skip the side measurement of compute_dtype 'fp32x3' on the same workload")
     ap.add_argument('--no-range-check', action='store_true', help='diagnostic: cfg.f16_range_check off -- no status-word wait at the end of a forward, so consecutive forwards are enqueued back to back')
@@ -828,7 +768,8 @@ def main():
             res['parity']['enforced'] = dtype in ('fp32', 'fp32x3')      # 'bf16' reports the error; the 1e-4 gate is the float32 modes'
         fwd_batch = {k: v[chunks[0][0]:chunks[0][1]] for k, v in batch.items()}
         if not args.no_roofline:
-            r = measure_kpconv_roofline(model, fwd_batch)
+            keep = {}
+            r = measure_kpconv_roofline(model, fwd_batch, keep=keep)
             traffic = pmc_traffic(args.pairs, args.points, args.shuffle, r, args.real) if (args.config == '3dmatch' and not args.parity_mode) else None
             gather = {'bound': 'hbm', 'achieved': r['achieved_gather_kernel_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': r['achieved_gather_kernel_GBs'] / HBM_PEAK_GBS, 'traffic': traffic, 'detail': r}
@@ -846,8 +787,30 @@ def main():
             res['config']['code'] = code_version()
             res['roofline'] = att if args.config == 'modelnet' else gather
             res['roofline_secondary'] = gather if args.config == 'modelnet' else att
-            res['roofline_gemm'] = measure_gemm_roofline(model, fwd_batch)
+            res['roofline_gemm'] = measure_gemm_roofline(model, fwd_batch, keep=keep)
             res['preprocess'] = measure_preprocess(model, fwd_batch)
+            # the WHOLE forward against its own roofline (round 6): compulsory bytes / 8 TB/s and the matrix-pipe time of every product at the
+            # peaks; the step can be no faster than the larger of the two.  And the HBM bytes the counters saw the forward move, next to them.
+            from regtr_amd.workload import forward_compulsory_bytes, forward_matrix_seconds
+            lv = res['preprocess']['level_points']
+            comp = forward_compulsory_bytes(model, lv, list(cfg.neighborhood_limits), lv[-1], cfg.d_embed)
+            terms_att = {3: 3}.get(model.transformer_encoder.layers[0].attn_precision, 6) if dtype in ('fp32', 'fp32x3') else (1 if dtype == 'bf16' else 6)
+            fm = forward_matrix_seconds(keep['gemm'][0], keep['gemm'][1], keep['gather'][0], keep['gather'][1], a['alg_flops_per_step'], terms_att)
+            t_matrix = fm['dense_s'] + fm['gather_s'] + fm['attention_s']
+            t_hbm = comp / (HBM_PEAK_GBS * 1e9)
+            fwd_ms = elapsed / args.steps / len(chunks) * 1e3
+            res['forward_roofline_frac'] = round(max(t_hbm, t_matrix) * 1e3 / fwd_ms, 4)
+            res['forward_roofline'] = {
+                'what': 'max(compulsory HBM bytes / 8 TB/s, matrix-pipe time of every product at the peaks) / measured time of one forward',
+                'forward_ms': round(fwd_ms, 3), 'hbm_ms': round(t_hbm * 1e3, 3), 'matrix_ms': round(t_matrix * 1e3, 3),
+                'matrix_ms_split': {'dense_products': round(fm['dense_s'] * 1e3, 3), 'kpconv_gather_correlation_f32_mfma': round(fm['gather_s'] * 1e3, 3), 'attention_core': round(fm['attention_s'] * 1e3, 3)},
+                'algorithmic_TFLOP': round(fm['algorithmic_flops'] / 1e12, 3), 'issued_TFLOP': round(fm['issued_flops'] / 1e12, 3),
+                'peaks': {'hbm_GBs': HBM_PEAK_GBS, 'mfma_16bit_dense_TFLOPs': MFMA_BF16_PEAK_TFS, 'mfma_f32_TFLOPs': 157.3},
+                'kernel_time_sum_ms': {'dense_products': res['roofline_gemm']['ms_per_step'], 'kpconv_gathers': round(r['gather_s_per_step'] * 1e3, 3),
+                                       'attention_core': round(a['attention_s_per_step'] * 1e3, 3), 'pyramid_alone': res['preprocess']['pyramid_ms_alone'],
+                                       'note': 'each family event-timed alone on ONE stream; their sum exceeds the step by what the two-stream forward overlaps'}}
+            res['forward_traffic'] = forward_traffic(args.pairs, args.points, args.shuffle, args.real, comp) if args.config == '3dmatch' and not args.parity_mode else \
+                {'hbm_GB': None, 'compulsory_GB': round(comp / 1e9, 3), 'ratio': None, 'top3': None, 'note': 'counter passes are kept for the default 3dmatch workload only'}
             # the candid companion of roofline.frac, at the top level: HBM bytes the COUNTERS saw per gather launch / launch time / peak
             res['counter_hbm_frac_of_peak'] = r.get('counter_hbm_frac_of_peak')
         if dtype not in ('fp32', 'fp32x3'):
@@ -892,6 +855,10 @@ def main():
             res['config']['fp32x3_same_workload'] = {'value': len(fwd_batch['src_xyz']) / t3, 'unit': 'pairs/s', 'ms_per_step': t3 * 1e3, 'steps': k3,
                                                      'max_abs_pose_vs_default': float((o3['pose'] - model(dict(fwd_batch))['pose']).abs().max())}
             del m3
+        if args.config == '3dmatch' and world == 1 and not args.real and not args.no_real and not args.parity_mode and args.points == 20000 and not args.shuffle:
+            # the same configuration on the REAL fragments the reference ships (demo.py:26-49), same pairs per forward, measured in this run outside
+            # the timed region: the synthetic rooms are calibrated to the red-kitchen pair's level sizes (regtr_amd/synthetic.py), this is the check
+            res['real_fragments_pairs_per_s'], res['real_fragments'] = measure_real_fragments(args, dev, dtype)
         if not args.no_cpu_baseline and world == 1:      # the CPU leg is reported by the single-GPU run only
             res['cpu_baseline'] = cpu_baseline(cfg, [pairs[i % len(pairs)] for i in range(24 if args.config == 'modelnet' else 6)],
                                                cfg_name='3dmatch' if lomatch else args.config)
@@ -910,6 +877,8 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and res.get('parity', {}).get('enforced') and not res.get('real_fragments', {}).get('parity', {}).get('ok', True):
+        sys.exit(f"bench.py: PARITY FAILED on the real-fragment batch -- {res['real_fragments']['parity']}")
     if rank == 0 and res.get('parity', {}).get('enforced') and not res['parity']['ok']:
         sys.exit(f"bench.py: PARITY FAILED -- {res['parity']}")
     if rank == 0 and not res.get('reduced_precision_error', {}).get('gate', {}).get('ok', True):

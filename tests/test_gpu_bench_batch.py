@@ -133,3 +133,22 @@ def test_f16_pair_operand_range_on_the_bench_workload():
     worst_a, worst_w = max(r[3] for r in log), max(r[4] for r in log)
     print(f'f16 pair: {len(log)} launches, largest |A| {worst_a:.1f} (shape {max(log, key=lambda r: r[3])[:3]}), largest |W| {worst_w:.2f}; limit 65504')
     assert worst_a < 65504 / 50 and worst_w < 65504 / 50
+
+
+@pytest.mark.parametrize('real', [False, True], ids=['synthetic', 'real_fragments'])
+def test_all_pairs_of_a_64_pair_forward_within_tolerance(real):
+    """The bench line's in-run gate checks 8 pairs of a forward; this is the ALL-PAIRS sweep as a test (round 5 ran it as a tool,
+    profiles/r05_z_parity_sweep.md: real fragments at 4.7e-5 pose / 6.7e-5 correspondences, a margin of 1.5-2 x that must not erode unseen):
+    every one of the 64 pairs of a default-mode forward -- synthetic rooms and the shipped real fragments -- against the CPU oracle on that
+    pair alone: key points bit-exact, correspondences and R|t <= 1e-4 (BASELINE.json north_star)."""
+    import bench
+    dev = torch.device('cuda', 0)
+    cfg, model, pairs, batch = bench.build_workload('3dmatch', 64, 20000, False, 0, dev, 'fp32', real=real)
+    out = model({'src_xyz': list(batch['src_xyz']), 'tgt_xyz': list(batch['tgt_xyz'])})
+    torch.cuda.synchronize()
+    par = bench.parity_check(cfg, model, pairs, out, list(range(64)))
+    worst_pose = max(par['per_pair'], key=lambda p: p['pose']); worst_corr = max(par['per_pair'], key=lambda p: p['corr'])
+    print(f"all 64 pairs ({'real fragments' if real else 'synthetic'}): pose <= {par['pose_max_abs']:.2e} (slot {worst_pose['slot']}), "
+          f"correspondences <= {par['corr_max_abs']:.2e} (slot {worst_corr['slot']}), Kabsch condition <= {par['kabsch_cond_max']:.1f}, {par['seconds']} s of oracle")
+    assert par['pairs_checked'] == 64 and len(par['per_pair']) == 64 and par['keypoints_bit_exact']
+    assert par['ok'] and par['pose_max_abs'] < 1e-4 and par['corr_max_abs'] < 1e-4, {k: par[k] for k in ('pose_max_abs', 'corr_max_abs', 'reason')}
