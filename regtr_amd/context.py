@@ -78,6 +78,18 @@ def current():
     return c if c is not None else _DEFAULT
 
 
+def set_thread_default(**kw):
+    """Replaces fields of THIS thread's base context (what applies outside any `with` block) and returns their previous values: the setter
+    behind cpp_wrappers.set_reference_order.  The process-wide default context is never mutated: a thread that has none gets its own copy."""
+    c = getattr(_tls, 'ctx', None)
+    if c is None:
+        c = _tls.ctx = _DEFAULT.derive()
+    prev = {k: getattr(c, k) for k in kw}
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return prev
+
+
 def forward(device, **kw):
     """`with context.forward(dev, f16_pair=..., status=...) as ctx:` -- a fresh context on this thread's stack.  Recording lists and the
     audit log of an enclosing context (bench.py / tests wrap model calls in `context.recording(...)`) are inherited."""

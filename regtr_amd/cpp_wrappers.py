@@ -18,10 +18,41 @@ import torch
 from . import _lib, context, ops
 
 
+class _ReferenceOrder:
+    """What `reference_order()` returns: a context manager.  Until round 4 `reference_order(True)` was a SETTER; a bare call of that kind is
+    now a no-op, so an instance that is dropped without ever being entered says so (RuntimeWarning) instead of silently leaving the caller
+    on the canonical row orders.  `set_reference_order(on)` is the setter for callers that cannot use a `with` block."""
+
+    def __init__(self, on):
+        self._on, self._ctx, self._entered = bool(on), None, False
+
+    def __enter__(self):
+        self._entered = True
+        self._ctx = context.current().derive(reference_order=self._on)
+        return self._ctx.__enter__()
+
+    def __exit__(self, *exc):
+        ctx, self._ctx = self._ctx, None
+        return ctx.__exit__(*exc)
+
+    def __del__(self):
+        if not self._entered:
+            import warnings
+            warnings.warn('cpp_wrappers.reference_order(...) was called but never entered: it is a context manager (`with cpp_wrappers.'
+                          'reference_order():`), the call alone changes nothing -- use cpp_wrappers.set_reference_order(on) for a setter',
+                          RuntimeWarning, stacklevel=2)
+
+
 def reference_order(on=True):
     """`with cpp_wrappers.reference_order():` -- both ops return the reference's own row orders (parity mode) for the calls made
     inside the block on this thread."""
-    return context.current().derive(reference_order=bool(on))
+    return _ReferenceOrder(on)
+
+
+def set_reference_order(on):
+    """Setter form (the pre-round-5 behaviour of `reference_order(True)`): switches this THREAD's base call context and returns the
+    previous value."""
+    return context.set_thread_default(reference_order=bool(on))['reference_order']
 
 
 def _ref_order():

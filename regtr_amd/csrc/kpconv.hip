@@ -875,6 +875,7 @@ __global__ void __launch_bounds__(256) k_maxpool_gather(const float* __restrict_
 // all issued before the first maximum.  Needs ns * C * 4 < 2^32 - 256 (32-bit unsigned buffer offsets; MP_OOB, not RG_OOB, is the out-of-range
 // offset here: the level-0 rows of a 192-pair forward are 3.7 GB, and with RG_OOB's 2 GiB bound that launch fell back to the predicated kernel
 // above -- 2.65 ms against 1.9 for three times the 64-pair launch).
+namespace {
 constexpr unsigned MP_OOB = 0xfffffff0u;
 template <int QW, int HB>
 __global__ void __launch_bounds__(256) k_maxpool_gather_buf(const float* __restrict__ x, int ns, int C, const int* __restrict__ nbr,
@@ -905,6 +906,7 @@ __global__ void __launch_bounds__(256) k_maxpool_gather_buf(const float* __restr
         if (q < nq) *(float4*)(out + (size_t)q * C + c) = m;
     }
 }
+}  // namespace
 
 extern "C" {
 

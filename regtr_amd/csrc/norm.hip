@@ -339,7 +339,7 @@ int regtr_instnorm_apply(const float* x, const int* seg_off, int n_clouds, int m
 }
 
 // out = a + b (float4 body, scalar tail): with_pos_embed of the post-norm encoder layer (transformers.py:118-119,131,142)
-__global__ void __launch_bounds__(256) k_add(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ out)
+static __global__ void __launch_bounds__(256) k_add(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ out)
 {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {

@@ -311,6 +311,13 @@ def _pool_fill(task):
     return b, part, ls, lt, ids, None
 
 
+def _unlink_quiet(path):
+    try:
+        os.unlink(path)
+    except OSError:
+        pass
+
+
 class LoaderPool:
     """`workers` forked loader processes + their shared slabs over one pair source; `iterate(indices, batch)` yields batches
     {'src_xyz': [...], 'tgt_xyz': [...], 'ids': [...]} of device tensors (CPU tensors for a cpu `device`: the tests' path), in order.
@@ -347,17 +354,20 @@ class LoaderPool:
         """The pair source the workers index (`pairs[i]` -> {'src_xyz', 'tgt_xyz', 'idx', ...}); must pickle."""
         import pickle
         import tempfile
+        import weakref
         self._drop_source_file()
         fd, self._source_file = tempfile.mkstemp(prefix='regtr_pairs_', suffix='.pkl')
         with os.fdopen(fd, 'wb') as f:
             pickle.dump(pairs, f, protocol=pickle.HIGHEST_PROTOCOL)
+        # sys.exit() / an exception / an abandoned pool: the file is removed when the pool is collected or the interpreter exits
+        self._source_finalizer = weakref.finalize(self, _unlink_quiet, self._source_file)
 
     def _drop_source_file(self):
         if self._source_file is not None:
-            try:
-                os.unlink(self._source_file)
-            except OSError:
-                pass
+            fin = getattr(self, '_source_finalizer', None)
+            if fin is not None:
+                fin.detach()
+            _unlink_quiet(self._source_file)
             self._source_file = None
 
     def prepare(self):

@@ -460,7 +460,7 @@ class KPFEncoder(nn.Module):
         ctx = context.current()
         return bool(ops.use_one_call_encoder and ctx.gather_records is None and ctx.gemm_records is None and ctx.f16_range_log is None
                     and not ops.force_f32_gemm and not ops.force_x3_gemm and ops.use_tile_info and ops.preapply_unary2 == 1
-                    and meta['points'][0].shape[0] < ops.SMALL_REGIME_ROWS and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
+                    and meta['points'][0].shape[0] < min(ops.SMALL_REGIME_ROWS, ops.STREAM_MIN_ROWS) and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0
                     and x.shape[0] > 0)
 
     def _block_table(self):

@@ -418,6 +418,9 @@ use_tile_info = devflags.on('REGTR_TILE_INFO')
 # fold would route to the tiled kernel (K > 64), 2 = everywhere, 0 = never
 preapply_unary2 = int(devflags.flag('REGTR_PREAPPLY_UNARY2', '1'))
 PREAPPLY_MIN_ROWS = 8192        # (a pair or two per forward is launch-bound: the fold saves the extra launch there)
+# csrc/encoder.hip sequences the small-batch regime with these rules compiled in (ENC_PREAPPLY_ROWS, no strip / block-tail form below
+# STREAM_MIN_ROWS): the one-call path equals the op-by-op path only while the gates nest like this (kpconv.KPFEncoder._one_call_ok)
+assert PREAPPLY_MIN_ROWS == 8192, 'csrc/encoder.hip compiles this gate in (ENC_PREAPPLY_ROWS)'      # (a REGTR_SMALL_ROWS override beyond STREAM_MIN_ROWS: _one_call_ok caps it)
 # the six cross-encoder layers enqueued by one C call (regtr_cross_encoder_fwd) instead of 72 op calls
 use_one_call_cross_encoder = devflags.on('REGTR_ONE_CALL_XENC')
 # the encoder's blocks enqueued by one C call (regtr_encoder_fwd) in the small-batch regime (< 65536 level-0 rows) instead of ~130 op calls

@@ -183,10 +183,12 @@ class RegTR(nn.Module):
 
     def _ones(self, n, dev):
         """RegTR's input features (regtr.py:136: ones, one per point) as a view of a cached buffer: constant data, a fill kernel and an
-        allocation less per forward."""
-        ent = self._cache.get(('ones', dev))
+        allocation less per forward.  One buffer per (device, stream), like the status word: created and regrown in stream order, so a second
+        thread / stream driving this model can neither read it before its fill kernel ran nor lose it to another stream's regrow."""
+        key = ('ones', dev, torch.cuda.current_stream(dev).cuda_stream)
+        ent = self._cache.get(key)
         if ent is None or ent.shape[0] < n:
-            ent = self._cache[('ones', dev)] = torch.ones((max(n, 1) * 5 // 4 + 16, 1), dtype=torch.float32, device=dev)
+            ent = self._cache[key] = torch.ones((max(n, 1) * 5 // 4 + 16, 1), dtype=torch.float32, device=dev)
         return ent[:n]
 
     def _side_stream(self, dev):
@@ -244,6 +246,16 @@ class RegTR(nn.Module):
             # only the pose is non-finite: the f16 pair products were all finite, so the arithmetic is not the cause -- a NaN / Inf in the
             # input clouds or the weights, or a degenerate pair.  A re-run in fp32x3 would return the same NaN at twice the cost.
             self.nonfinite_pose_forwards += 1
+            if self.nonfinite_pose_forwards == 1 and self._f16_pair:
+                # ... the FIRST time, checked instead of assumed: one re-run with six-term bf16 splits.  A finite pose there means an f16 pair
+                # kernel produced a degenerate result WITHOUT raising its range bit -- a defect to report, and the finite result is returned.
+                with context.forward(dev, f16_pair=False, force_x3=True, status=None):
+                    again = self._forward(batch, dev)
+                if bool(torch.isfinite(again['pose']).all()):
+                    self.logger.error("non-finite pose with NO f16 range bit set, but the fp32x3 re-run is finite: an f16 pair kernel missed its "
+                                      "range report (status %d) -- returning the fp32x3 result; set cfg.compute_dtype: fp32x3 and report this", bits)
+                    return again
+                self.logger.warning('non-finite pose (status %d): the fp32x3 re-run is non-finite too -- the inputs or the checkpoint hold NaN / Inf', bits)
             if _throttled(self.nonfinite_pose_forwards):
                 self.logger.warning('non-finite pose in the output (status %d; forward no. %d with this condition): every f16 pair product was '
                                     'finite, so check the input clouds and the checkpoint for NaN / Inf -- returned as is, not re-run',

@@ -143,6 +143,9 @@ def main():
     # idle until run_test hands them batches (nothing is read ahead of the timed loop); the pair source reaches them by file later.
     workers = opt.num_workers if opt.num_workers >= 0 else 4
     pool = harness.LoaderPool(None, device, workers=workers, max_batch=opt.batch) if workers > 0 else None
+    if pool is not None:
+        import atexit
+        atexit.register(pool.close)      # every sys.exit() / exception path below: workers ended, the pair-source file removed (close is idempotent)
     torch.cuda.set_device(device)
     if opt.alloc_conf:
         torch.cuda.memory._set_allocator_settings(opt.alloc_conf)

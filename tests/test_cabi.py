@@ -29,6 +29,10 @@ def test_library_exports_every_declared_symbol():
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(re.findall(r'\bT (regtr_\w+)', out)))
     assert exported == names, set(exported) ^ set(names)
+    # ... and NOTHING else that is code or a kernel handle: every kernel lives in an anonymous namespace / is static (round 5 shipped
+    # `__device_stub__k_add` and the k_maxpool_gather_buf<> stubs beside the ABI).  Left over: the HIP fat-binary bookkeeping symbols.
+    stray = [l.split()[-1] for l in out.splitlines() if l.split() and not re.match(r'regtr_\w+$|__hip_cuid_\w+$|_(_)?(init|fini|edata|end|bss_start)$', l.split()[-1])]
+    assert not stray, f'libregtr_hip.so exports symbols outside include/regtr_hip.h: {stray}'
     from regtr_amd import experimental
     exp = _header_symbols('regtr_hip_experimental.h')
     assert sorted(experimental.SIGNATURES) == exp and not set(exp) & set(names)
@@ -169,3 +173,31 @@ def test_kernel_points_loader_matches_reference_recipe():
     exp = np.matmul(0.0625 * (K015_CENTER + np.random.normal(scale=0.01, size=(15, 3))), R).astype(np.float32)
     assert np.array_equal(kp, exp)
     assert np.allclose(np.linalg.norm(K015_CENTER[1:], axis=1).mean(), 0.66, atol=0.02)
+
+
+def test_reference_order_bare_call_warns_and_setter_is_thread_local():
+    """`cpp_wrappers.reference_order(True)` used to be a setter; as a context manager a bare call changes nothing, so it must say
+    so; `set_reference_order` is the setter, and it touches the calling thread only."""
+    import gc
+    import threading
+    import warnings
+    from regtr_amd import context, cpp_wrappers
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        cpp_wrappers.reference_order(True)          # never entered
+        gc.collect()
+    assert any('never entered' in str(x.message) for x in w)
+    assert not context.current().reference_order
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        with cpp_wrappers.reference_order():
+            assert context.current().reference_order
+        gc.collect()
+    assert not w and not context.current().reference_order
+    seen = []
+    def other():
+        seen.append(context.current().reference_order)
+    assert cpp_wrappers.set_reference_order(True) is False and context.current().reference_order
+    t = threading.Thread(target=other); t.start(); t.join()
+    assert seen == [False]
+    assert cpp_wrappers.set_reference_order(False) is True and not context.current().reference_order

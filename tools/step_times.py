@@ -1,5 +1,5 @@
 """GPU: wall time of every forward of a long run (is a step's time a function of how long the chip has been busy?).
-    python tools/step_times.py [pairs] [steps]"""
+    python tools/step_times.py [pairs] [steps] [real] [nosync]   (nosync: forwards enqueued back to back, timed in groups of five)"""
 import os
 import sys
 import time
@@ -12,14 +12,18 @@ import bench  # noqa: E402
 
 pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+real, nosync = 'real' in sys.argv[3:], 'nosync' in sys.argv[3:]
 dev = torch.device('cuda:0')
-cfg, model, prs, batch = bench.build_workload('3dmatch', pairs, 20000, False, 0, dev, 'fp32')
+cfg, model, prs, batch = bench.build_workload('3dmatch', pairs, 20000, False, 0, dev, 'fp32', real=real)
 ts = []
+group = 5 if nosync else 1
 with torch.no_grad():
-    for i in range(steps):
+    for i in range(0, steps, group):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        model({'src_xyz': batch['src_xyz'], 'tgt_xyz': batch['tgt_xyz']})
-        torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        for _ in range(group):
+            model({'src_xyz': batch['src_xyz'], 'tgt_xyz': batch['tgt_xyz']})
+        torch.cuda.synchronize(); ts += [(time.perf_counter() - t0) * 1e3 / group] * group
+print('peak GiB', round(torch.cuda.max_memory_allocated() / 2**30, 2), 'reserved GiB', round(torch.cuda.memory_reserved() / 2**30, 2))
 ts = np.array(ts)
 print(f'{pairs} pairs per forward, {steps} forwards, ms per forward:')
 for i in range(0, steps, 10):
