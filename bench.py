@@ -520,20 +520,29 @@ def parity_check(cfg, model, pairs, out, which, parity_mode=False):
 def plan_pairs(args, rank, world, device):
     """Which pairs this rank runs and how they are cut into forwards.  Weak scaling (default): `--pairs` pairs per rank and step, ids
     rank * pairs + i.  --config lomatch (configs[3], strong scaling): a fixed set of --total-pairs pairs, pair i -> rank i % world
-    (regtr_amd/distributed.py: shard_pairs), `--pairs` per forward with a ragged last forward.
+    (regtr_amd/distributed.py: shard_pairs), cut into the fewest forwards of at most `--pairs` pairs and then into EQUAL ones (a 223-pair
+    shard at 192 per forward is 112 + 111, not 192 + 31: a short last forward runs at a fraction of the per-pair rate).
+    --emulate-rank-of W: this ONE GPU runs rank 0's shard of a W-rank job (pair i with i % W == 0) -- the per-rank time of a strong-scaling
+    run without the node; the line reports it as a PREDICTION.
     -> (lomatch, per_fwd, pair_ids (n_local,) i32 on `device`, chunks [(lo, hi)], pairs_per_step over all ranks)"""
     from regtr_amd.distributed import shard_pairs
     lomatch = args.config == 'lomatch'
     per_fwd = args.pairs if args.pairs else DEFAULT_PAIRS[args.config]
     args.pairs = per_fwd
+    emu = getattr(args, 'emulate_rank_of', 0)
     if lomatch:
-        mine = shard_pairs(args.total_pairs, rank, world)
+        mine = shard_pairs(args.total_pairs, 0, emu) if emu else shard_pairs(args.total_pairs, rank, world)
         pair_ids = torch.tensor(mine, device=device, dtype=torch.int32)
     else:
         pair_ids = torch.arange(per_fwd, device=device, dtype=torch.int32) + rank * per_fwd
     n_local = int(pair_ids.numel())
-    chunks = [(lo, min(lo + per_fwd, n_local)) for lo in range(0, n_local, per_fwd)]
-    return lomatch, per_fwd, pair_ids, chunks, (args.total_pairs if lomatch else per_fwd * world)
+    n_fwd = max(1, -(-n_local // per_fwd))
+    base, extra = divmod(n_local, n_fwd)
+    chunks, lo = [], 0
+    for i in range(n_fwd):
+        hi = lo + base + (1 if i < extra else 0)
+        chunks.append((lo, hi)); lo = hi
+    return lomatch, per_fwd, pair_ids, chunks, (n_local if emu else (args.total_pairs if lomatch else per_fwd * world))
 
 
 def settle_device(step, budget_s, sync=None):
@@ -558,7 +567,7 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     rank through ONE all_gather (regtr_amd/distributed.py) -- per pass over the set for lomatch, once at the end of the timed region
     otherwise.  step() -> (poses (n_local, 3, 4) of this rank's pairs, anything).  -> (elapsed s, all poses, all ids, last step's extra)"""
     from regtr_amd.distributed import gather_poses
-    n_set = args.total_pairs if lomatch else int(pair_ids.numel()) * (dist.get_world_size() if dist else 1)      # (weak scaling: every rank holds the same count)
+    n_set = int(pair_ids.numel()) if getattr(args, 'emulate_rank_of', 0) else (args.total_pairs if lomatch else int(pair_ids.numel()) * (dist.get_world_size() if dist else 1))      # (weak scaling: every rank holds the same count)
     gather = (lambda p: gather_poses(p.reshape(-1, 12), pair_ids, n_set)) if dist else (lambda p: (p.reshape(-1, 12), pair_ids))
     warm = None
     for _ in range(args.warmup):
@@ -630,11 +639,14 @@ def main():
                     help='3dmatch = BASELINE configs[2] (the headline metric); modelnet = configs[1] (ModelNet-size pairs, bf16 cross-encoder); '
                          'lomatch = configs[3]: --total-pairs 10-30 %%-overlap pairs sharded over the ranks (strong scaling), a step = one pass over the set')
     ap.add_argument('--total-pairs', type=int, default=1781, help='lomatch: size of the pair set (3DLoMatch test list: 1781)')
+    ap.add_argument('--emulate-rank-of', type=int, default=0, metavar='W',
+                    help='lomatch: run rank 0\'s shard of a W-rank job (pairs i %% W == 0) on this one GPU, pose gather through a one-rank RCCL group included, and report '
+                         'predicted_pairs_per_s = total pairs / shard time -- a strong-scaling PREDICTION for W GPUs, flagged as such (no multi-GPU node needed)')
     ap.add_argument('--distinct-pairs', type=int, default=128, help='lomatch: different synthetic pairs generated per rank (cycled; set-up time only)')
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
     ap.add_argument('--parity-pairs', type=int, default=8, help='pairs of the last timed step checked against the CPU oracle: first, last, largest, smallest slot of the batch + evenly spaced others (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
-    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 192 for 3dmatch, 256 for modelnet, 64 per forward for lomatch; pairs are independent, 288 GB of HBM holds far more)')
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 192 for 3dmatch, 256 for modelnet, at most 192 per forward for lomatch -- a shard is cut into equal forwards; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--real', action='store_true', help='3dmatch: the three REAL pairs the reference ships (demo.py:26-49; tests/golden fixtures) replicated to --pairs under random rigid motions, instead of synthetic rooms')
@@ -681,6 +693,13 @@ def main():
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs')
     stub = args.stub_backend is not None      # tests only: the multi-process entry logic on CPU (gloo), no kernels
     dist = None
+    if args.emulate_rank_of:
+        if args.config != 'lomatch' or args.gpus != 1 or args.emulate_rank_of < 1:
+            ap.error('--emulate-rank-of W needs --config lomatch on one GPU')
+        if 'RANK' not in os.environ:              # a one-rank RCCL group of our own, so that the shard's pose gather is the real collective
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                os.environ.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(sk.getsockname()[1]))
     if world > 1 or 'RANK' in os.environ:        # launched by torch.distributed.run: a process group even at one rank (RCCL init, the
         import torch.distributed as dist        # device-tensor all_gather) -- the same code path at every world size
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -733,8 +752,8 @@ def main():
                 workload = f'BASELINE configs[4]-style stress: ~{args.points}-point clouds, conf/3dmatch.yaml pipeline'
             if lomatch:
                 metric = 'point-cloud pairs/sec (3DLoMatch-like set, ~20k pts, overlap 10-30 %)'
-                workload = (f'BASELINE configs[3]: {args.total_pairs} 3DLoMatch-like pairs (overlap 10-30 %) sharded pair i -> rank i % {world}, '
-                            f'{per_fwd} pairs per forward, one RCCL pose all_gather per pass; a step = one pass over the set '
+                workload = (f'BASELINE configs[3]: {args.total_pairs} 3DLoMatch-like pairs (overlap 10-30 %) sharded pair i -> rank i % {args.emulate_rank_of or world}, '
+                            f'forwards of {[hi - lo for lo, hi in chunks]} pairs on rank 0, one RCCL pose all_gather per pass; a step = one pass over the ' + ('SHARD of rank 0 (emulation) ' if args.emulate_rank_of else 'set ') +
                             f'({min(args.distinct_pairs, n_local)} distinct synthetic pairs per rank, cycled)')
             if args.real:
                 metric = 'point-cloud pairs/sec (3DMatch REAL fragments, ~17-25k pts)'
@@ -760,6 +779,14 @@ def main():
                                       'bf16x2': 'bf16 three-term split in the cross-encoder Linears, bf16x3 elsewhere',
                                       'bf16': 'plain bf16 operands in the cross-encoder Linears and attention core, float32-grade elsewhere'}[dtype]},
         }
+        if args.emulate_rank_of:
+            W = args.emulate_rank_of
+            res['predicted'] = {
+                'world': W, 'predicted_pairs_per_s': args.total_pairs / (elapsed / args.steps), 'shard_pairs': n_local, 'shard_ms': elapsed / args.steps * 1e3,
+                'forwards_per_shard': [hi - lo for lo, hi in chunks],
+                'PREDICTION': f'rank 0\'s shard of a {W}-rank pass over the {args.total_pairs}-pair set, timed on ONE GPU with the pose gather through a one-rank RCCL group: '
+                              f'a {W}-GPU pass takes at least this long (largest shard; the {W}-rank all_gather moves {W} x {-(-args.total_pairs // W)} x 52 bytes over xGMI instead of one '
+                              'rank\'s rows, and the ranks share the host).  NOT a measurement of a multi-GPU run.'}
         if args.parity_pairs > 0:
             # "pose err vs ref" (BASELINE.json metric): the last timed forward's outputs against the CPU oracle, >= 2 pairs
             lo, hi = chunks[-1]

@@ -218,10 +218,30 @@ __global__ void __launch_bounds__(256) k_clear_tables(const int* __restrict__ n_
     if (first) first[h] = 0x7F7F7F7F;
 }
 
+#ifndef RG_RANK2
+#define RG_RANK2 1            // development A/B (REGTR_VARIANT_FLAGS=-DRG_RANK2=0): for_each_ranked below
+#endif
+constexpr int CELL_BITS = 21;
+constexpr int64_t CELL_BIAS = 1 << 20;
+
+// Home slot of a key: the plain 64-bit mix, salted with the cloud.
+// (Measured and dropped, round 6: BLOCK-LOCAL homes for the cell keys of the radius grid -- the 4 x 4 x 4 block of cells picks a 64-slot region,
+//  the cell's position in its block the slot inside it -- so that the 27 probes of a neighbourhood fall into <= 8 regions of 2 KB instead of 27 random
+//  lines of a table of up to 537 MB, a wave's slot run is one spatial block and the cell-sorted supports are spatially coherent.  Tables bit-identical;
+//  192-pair pyramid 12.17 -> 18.46 ms: k_radius_query_self 1219 -> 2533 us per launch, k_radius_query 788 -> 1105, k_insert 267 -> 278
+//  (profiles/r06_d_block_hash.md).  A planar surface fills CONTIGUOUS runs of 16 slots of its region; where two blocks share a region a probe walks such a
+//  run, and a wave waits for the slowest of its 27 probing lanes -- most neighbourhoods then pay 5-10 dependent round trips instead of 1-2; and the
+//  occupied slots bunch into 27 % of the regions, so the cell-centric kernel's slot runs are badly balanced.  The locality bought nothing even where
+//  neither effect applies (k_insert): these kernels wait on dependent round trips and issue slots, not on HBM bytes.)
+__device__ __forceinline__ unsigned rg_home_slot(uint64_t key, int cid, unsigned mask)
+{
+    return rg_hash64(key ^ ((uint64_t)(cid + 1) * 0x9E3779B97F4A7C15ULL)) & mask;
+}
+
 __device__ __forceinline__ int hash_insert(int* __restrict__ rep, unsigned mask, const uint64_t* __restrict__ pkey,
                                            const int* __restrict__ pcid, int i, uint64_t key, int cid)
 {
-    unsigned h = rg_hash64(key ^ ((uint64_t)(cid + 1) * 0x9E3779B97F4A7C15ULL)) & mask;
+    unsigned h = rg_home_slot(key, cid, mask);
     for (;;) {
         int r = __hip_atomic_load(&rep[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r < 0) {
@@ -468,9 +488,6 @@ __global__ void k_out_offsets(const int* __restrict__ seg_off, int n_clouds, con
 // ------------------------------------------------------------------------------------------------
 // cell grid over support points + radius query
 // ------------------------------------------------------------------------------------------------
-constexpr int CELL_BITS = 21;
-constexpr int64_t CELL_BIAS = 1 << 20;
-
 __device__ __forceinline__ void cell_of(float x, float y, float z, double inv_cs, int64_t& cx, int64_t& cy, int64_t& cz)
 {
     cx = (int64_t)floor((double)x * inv_cs);
@@ -556,7 +573,7 @@ __global__ void __launch_bounds__(256) k_pack_slots(const int* __restrict__ rep,
 __device__ __forceinline__ void slot_find(const CellSlot* __restrict__ slots, unsigned mask, uint64_t key, int cid, int& cnt,
                                           int& start)
 {
-    unsigned h = rg_hash64(key ^ ((uint64_t)(cid + 1) * 0x9E3779B97F4A7C15ULL)) & mask;
+    unsigned h = rg_home_slot(key, cid, mask);
     cnt = 0; start = 0;
     for (;;) {
         const uint4 a = *(const uint4*)&slots[h];                 // key | cid | used
@@ -580,10 +597,32 @@ constexpr int QUERY_WAVES = 4;  // queries in flight per 256-thread workgroup
 // The keys are read EIGHT per step as four independent 16-byte broadcast reads with one wait: a one-key-per-iteration loop
 // (ds_read_b64, s_waitcnt lgkmcnt(0), compare) exposes a full LDS round trip per key -- ~100 cycles x ~30 keys per query was
 // most of the radius search's time.  The tail is padded with +inf keys, which rank below nothing.
+// Lists of <= 32 keys (a ball holds ~30 supports at 3DMatch densities: nine rows in ten) are ranked by TWO lanes per key (round 6): lane e
+// counts the keys below its own among keys 0..15, lane e + 32 among keys 16..31 -- two 8-key steps instead of four, the halves joined by
+// one v_permlane32_swap.  The compare-and-count steps are half of the vector instructions a query costs.
+#define RG_LT(lo, hi) ((((uint64_t)(hi) << 32) | (lo)) < mine ? 1 : 0)
 template <typename F>
 __device__ __forceinline__ void for_each_ranked(uint64_t* list, int n, F&& f)
 {
     const int lane = rg_lane();
+    if (RG_RANK2 && n <= 32) {                       // wave-uniform
+        if (lane >= n && lane < 32) list[lane] = ~0ULL;
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t mine = list[lane & 31];
+        const uint64_t* part = list + ((lane >> 5) << 4);
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j += 8) {
+            const uint4 a = *(const uint4*)(part + j), b = *(const uint4*)(part + j + 2), c = *(const uint4*)(part + j + 4),
+                        d = *(const uint4*)(part + j + 6);
+            rank += RG_LT(a.x, a.y) + RG_LT(a.z, a.w) + RG_LT(b.x, b.y) + RG_LT(b.z, b.w) + RG_LT(c.x, c.y) + RG_LT(c.z, c.w) +
+                    RG_LT(d.x, d.y) + RG_LT(d.z, d.w);
+        }
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)rank, (unsigned)rank, false, false);
+        rank = (int)(r[0] + r[1]);
+        if (lane < n) f(rank, mine);
+        return;
+    }
     const int np = (n + 7) & ~7;
     if (lane < np - n) list[n + lane] = ~0ULL;
     __builtin_amdgcn_wave_barrier();
@@ -594,14 +633,13 @@ __device__ __forceinline__ void for_each_ranked(uint64_t* list, int n, F&& f)
         for (int j = 0; j < np; j += 8) {
             const uint4 a = *(const uint4*)(list + j), b = *(const uint4*)(list + j + 2), c = *(const uint4*)(list + j + 4),
                         d = *(const uint4*)(list + j + 6);
-#define RG_LT(lo, hi) ((((uint64_t)(hi) << 32) | (lo)) < mine ? 1 : 0)
             rank += RG_LT(a.x, a.y) + RG_LT(a.z, a.w) + RG_LT(b.x, b.y) + RG_LT(b.z, b.w) + RG_LT(c.x, c.y) + RG_LT(c.z, c.w) +
                     RG_LT(d.x, d.y) + RG_LT(d.z, d.w);
-#undef RG_LT
         }
         if (e < n) f(rank, mine);
     }
 }
+#undef RG_LT
 
 __global__ void __launch_bounds__(QUERY_WAVES * RG_WAVE)
 k_radius_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_off, const int* __restrict__ s_seg_off,
