@@ -32,8 +32,8 @@ def test_world_size_mismatch_is_an_error():
 
 
 def test_lomatch_set_is_sharded_and_gathered_every_pass():
-    """--config lomatch (BASELINE configs[3]): 23 pairs over 2 ranks (12 + 11: ragged shards), 5 per forward (ragged last forward),
-    every pose back on every rank in pair-id order after each pass; strong scaling is what the line says."""
+    """--config lomatch (BASELINE configs[3]): 23 pairs over 2 ranks (12 + 11: ragged shards), at most 5 per forward (rank 0: 4 + 4 + 4, equal
+    forwards), every pose back on every rank in pair-id order after each pass; strong scaling is what the line says."""
     r = _run(['--gpus', '2', '--config', 'lomatch', '--total-pairs', '23', '--pairs', '5', '--steps', '2', '--warmup', '1', '--stub-backend', 'gloo'])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
@@ -42,12 +42,12 @@ def test_lomatch_set_is_sharded_and_gathered_every_pass():
 
 def test_lomatch_1781_pairs_on_eight_ranks():
     """The world-8 rehearsal of configs[3] that needs no 8-GPU node: `bench.py --gpus 8 --config lomatch --total-pairs 1781` on gloo with the
-    stand-in forward -- 223 / 222-row shards (ragged), 64 per forward (4 forwards per pass on every rank, the last one ragged), every pose
+    stand-in forward -- 223 / 222-row shards (ragged), at most 192 per forward cut into EQUAL forwards (112 + 111 on rank 0), every pose
     on every rank in pair order after each pass (asserted inside run_stub), eight ranks seen through the gather."""
     r = _run(['--gpus', '8', '--config', 'lomatch', '--total-pairs', '1781', '--steps', '2', '--warmup', '1', '--stub-backend', 'gloo'])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert d['n_gpus'] == 8 and d['pairs_per_step'] == 1781 and d['forwards_per_step_rank0'] == 4 and d['scaling'] == 'strong'
+    assert d['n_gpus'] == 8 and d['pairs_per_step'] == 1781 and d['forwards_per_step_rank0'] == 2 and d['scaling'] == 'strong'
     assert len(d['per_rank_ms_per_step']) == 8
 
 
@@ -129,4 +129,23 @@ def test_settle_phase_has_a_fixed_length_and_reports_its_passes():
     r = bench.settle_device(lambda: (calls.append(1), time.sleep(0.01)), 0.15, sync=lambda: None)
     assert r['passes'] == len(calls) >= 5 and 0.15 <= r['seconds'] < 1.0 and len(r['first_ms']) == 3 and all(t >= 9.0 for t in r['last_ms'])
     assert bench.settle_device(lambda: calls.append(1), 0.0, sync=lambda: None)['passes'] == 0
-    assert bench.DEFAULT_PAIRS == {'3dmatch': 192, 'modelnet': 256, 'lomatch': 64} and bench.REDUCED_TOL['pose'] <= 0.1
+    assert bench.DEFAULT_PAIRS == {'3dmatch': 192, 'modelnet': 256, 'lomatch': 192} and bench.REDUCED_TOL['pose'] <= 0.1
+
+
+def test_plan_pairs_equal_forwards_and_rank_emulation():
+    """bench.plan_pairs: a lomatch shard is cut into the fewest forwards of at most --pairs pairs, then into EQUAL ones (223 -> 112 + 111, not
+    192 + 31); --emulate-rank-of 8 gives one GPU rank 0's shard of an 8-rank job (the strong-scaling prediction of DESIGN section 7)."""
+    import argparse
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    a = argparse.Namespace(config='lomatch', pairs=0, total_pairs=1781, emulate_rank_of=8)
+    lomatch, per_fwd, ids, chunks, per_step = bench.plan_pairs(a, 0, 1, torch.device('cpu'))
+    assert lomatch and per_fwd == 192 and ids.tolist() == list(range(0, 1781, 8)) and chunks == [(0, 112), (112, 223)] and per_step == 223
+    a = argparse.Namespace(config='lomatch', pairs=64, total_pairs=1781, emulate_rank_of=0)
+    _, _, ids, chunks, per_step = bench.plan_pairs(a, 3, 8, torch.device('cpu'))
+    assert ids.tolist() == list(range(3, 1781, 8)) and [hi - lo for lo, hi in chunks] == [56, 56, 56, 55] and per_step == 1781
+    a = argparse.Namespace(config='3dmatch', pairs=0, total_pairs=1781, emulate_rank_of=0)
+    _, per_fwd, ids, chunks, per_step = bench.plan_pairs(a, 1, 2, torch.device('cpu'))
+    assert per_fwd == 192 and ids[0] == 192 and chunks == [(0, 192)] and per_step == 384
