@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(KS * RG_WAVE) __attribute__((amdgpu_waves_per_
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
-constexpr int BW = 4;                 // waves (32-query tiles) per workgroup
+constexpr int BW = 4;                 // waves (32-query tiles) per workgroup; clouds of more than 128 tokens: BW8 = 8 (round 6, below)
+constexpr int BW8 = 8;
 constexpr int BROW = 64;              // bytes per LDS row
 
 __device__ __forceinline__ unsigned bf_pack(float a, float b)
@@ -211,6 +212,9 @@ constexpr float MHA_F16_SCALE = 2048.f;
 // already packs most of the scalar form.)
 #ifndef MHA_WAVES_ATTR
 #define MHA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3)))
+#endif
+#ifndef MHA_WIDE
+#define MHA_WIDE 1                    // 8-wave workgroups for clouds of more than 128 tokens (A/B: -DMHA_WIDE=0)
 #endif
 #ifndef MHA_OPT_SWAP
 #define MHA_OPT_SWAP 1
@@ -297,11 +301,16 @@ __device__ __forceinline__ float mha_sum_halves(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <int NP, bool F16 = false>
+// NW (round 6) = waves per workgroup, 4 or 8.  Every workgroup of a (cloud, head) stages ALL of the cloud's K / V tiles, so the split + staging
+// work per query tile -- ~900 of the ~3200 cycles a wave spends per key tile in the f16 pair form -- is divided by the waves that share it: with
+// eight waves a thread stages one float2 of K and one key pair of ONE V channel (two split calls, one 4-byte LDS store per plane each) instead of a
+// float4 and two channels.  Same registers per wave, same 16 KB of LDS, two workgroups per CU instead of four; identical arithmetic per query, so
+// the outputs are bit-identical to the four-wave form.  The launcher takes eight waves when a cloud needs more than one 4-wave workgroup anyway.
+template <int NP, bool F16 = false, int NW = BW>
 // (waves_per_eu: with a register budget of at most 256 per lane hipcc keeps the MFMA accumulators in VGPRs; without it the budget is 512, the
 //  accumulators go to AGPRs and every softmax step pays v_accvgpr_read / _write copies -- 288 of the 1151 vector instructions of the f16 pair
 //  form, and 160 registers instead of 124: three waves per SIMD instead of four)
-__global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(MhaArgs g)
+__global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(MhaArgs g)
 {
     __shared__ __align__(16) unsigned char Ks[2][NP][TK * BROW];      // [buffer][plane][key][32 channels]
     __shared__ __align__(16) unsigned char Vt[2][NP][HD * BROW];      // [buffer][plane][channel][32 key slots]
@@ -309,8 +318,8 @@ __global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int cloud = blockIdx.z, head = blockIdx.y;
     const int q_begin = g.seg_off[cloud], q_end = g.seg_off[cloud + 1];
-    if (q_begin + (int)blockIdx.x * BW * TQ >= q_end) return;          // the whole workgroup (before any barrier)
-    const int q0 = q_begin + (blockIdx.x * BW + wave) * TQ;
+    if (q_begin + (int)blockIdx.x * NW * TQ >= q_end) return;          // the whole workgroup (before any barrier)
+    const int q0 = q_begin + (blockIdx.x * NW + wave) * TQ;
     const bool wave_live = q0 < q_end;                                 // wave-uniform; dead waves still stage K / V
     const int kc = g.kv_of[cloud];
     const int k_begin = g.seg_off[kc], nk = g.seg_off[kc + 1] - k_begin;
@@ -337,10 +346,12 @@ __global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
         }
     }
 
-    // staging roles: K -- thread (key = t / 8, channels 4 (t % 8) ..+3); V -- thread (key pair u = t / 16, channels 2 (t % 16), +1)
-    const int skey = t >> 3, sd4 = (t & 7) * 4;
-    const int su = t >> 4, sd2 = (t & 15) * 2;
-    const unsigned k_dst = (unsigned)skey * BROW + (((unsigned)(sd4 >> 3) ^ (((unsigned)skey >> 2) & 3u)) * 16u) + ((unsigned)t & 1u) * 8u;
+    // staging roles.  NW = 4: K -- thread (key = t / 8, channels 4 (t % 8) ..+3); V -- thread (key pair u = t / 16, channels 2 (t % 16), +1)
+    //                 NW = 8: K -- thread (key = t / 16, channels 2 (t % 16), +1);  V -- thread (key pair u = t / 32, channel t % 32)
+    constexpr int KPT = NW == 4 ? 4 : 2;                             // K channels per thread
+    const int skey = t / (32 / KPT), sdk = (t % (32 / KPT)) * KPT;
+    const int su = NW == 4 ? t >> 4 : t >> 5, sd2 = NW == 4 ? (t & 15) * 2 : (t & 31);
+    const unsigned k_dst = (unsigned)skey * BROW + (((unsigned)(sdk >> 3) ^ (((unsigned)skey >> 2) & 3u)) * 16u) + ((unsigned)sdk & 7u) * 2u;
     const unsigned vpos = ((2u * su) & 0x13u) | (((2u * su) & 4u) << 1) | (((2u * su) & 8u) >> 1);     // slot of key 2 u (even)
     unsigned v_dst[2];
 #pragma unroll
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
     // K / V rows travel global -> registers -> (split) -> LDS.  TWO register sets: the rows of tile t + 2 are requested while tile t
     // is multiplied and tile t + 1's set -- requested a whole tile earlier -- is split and stored; with one set the store pass waited
     // ~700 cycles per tile for loads issued one compute phase before (phase clocks, profiles/r03_mha_phase_clocks.md).
-    struct KV { float4 k; float2 v0, v1; };
+    struct KV { float4 k; float2 v0, v1; };             // (NW = 8: k.x, k.y and v0.x, v1.x only)
     // BRANCH-FREE loads from clamped rows: a predicated load (`x = 0; if (row < nk) x = load`) becomes load + select, and the select's
     // wait exposes the whole L2 latency right at the issue point -- phase clocks showed 1575 of 4800 cycles per key tile there.  Keys past
     // nk need no zeroing: their scores are masked to -inf below, so their (finite, clamped-row) values meet p = 0.
@@ -359,22 +370,34 @@ __global__ void __launch_bounds__(BW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
     const int kb = nk > 0 ? k_begin : q_begin;         // an empty key cloud: read (and never use) a row of the live query cloud
     auto fetch = [&](KV& r, int kt) {
         const int kr = min(kt + skey, nk1), v0 = min(kt + 2 * su, nk1), v1 = min(kt + 2 * su + 1, nk1);
-        r.k = *(const float4*)(g.k + (size_t)(kb + kr) * g.ldk + hoff + sd4);
-        r.v0 = *(const float2*)(g.v + (size_t)(kb + v0) * g.ldv + hoff + sd2);
-        r.v1 = *(const float2*)(g.v + (size_t)(kb + v1) * g.ldv + hoff + sd2);
+        if constexpr (NW == 4) {
+            r.k = *(const float4*)(g.k + (size_t)(kb + kr) * g.ldk + hoff + sdk);
+            r.v0 = *(const float2*)(g.v + (size_t)(kb + v0) * g.ldv + hoff + sd2);
+            r.v1 = *(const float2*)(g.v + (size_t)(kb + v1) * g.ldv + hoff + sd2);
+        } else {
+            const float2 k2 = *(const float2*)(g.k + (size_t)(kb + kr) * g.ldk + hoff + sdk);
+            r.k.x = k2.x; r.k.y = k2.y;
+            r.v0.x = g.v[(size_t)(kb + v0) * g.ldv + hoff + sd2];
+            r.v1.x = g.v[(size_t)(kb + v1) * g.ldv + hoff + sd2];
+        }
     };
     auto stage = [&](const KV& r, int buf) {
         unsigned a[NP], b[NP];
         bf_split2<NP, F16>(r.k.x, r.k.y, a);
-        bf_split2<NP, F16>(r.k.z, r.k.w, b);
+        if constexpr (NW == 4) {
+            bf_split2<NP, F16>(r.k.z, r.k.w, b);
 #pragma unroll
-        for (int p = 0; p < NP; p++) *(uint2*)(&Ks[buf][p][k_dst]) = make_uint2(a[p], b[p]);
+            for (int p = 0; p < NP; p++) *(uint2*)(&Ks[buf][p][k_dst]) = make_uint2(a[p], b[p]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NP; p++) *(unsigned*)(&Ks[buf][p][k_dst]) = a[p];
+        }
         bf_split2<NP, F16>(r.v0.x, r.v1.x, a);        // (key 2u, key 2u + 1) of channel sd2
-        bf_split2<NP, F16>(r.v0.y, r.v1.y, b);        // ... of channel sd2 + 1
+        if constexpr (NW == 4) bf_split2<NP, F16>(r.v0.y, r.v1.y, b);        // ... of channel sd2 + 1
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             *(unsigned*)(&Vt[buf][p][v_dst[0]]) = a[p];
-            *(unsigned*)(&Vt[buf][p][v_dst[1]]) = b[p];
+            if constexpr (NW == 4) *(unsigned*)(&Vt[buf][p][v_dst[1]]) = b[p];
         }
     };
 
@@ -660,10 +683,21 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
     }
     else {
         if ((ldv % 2) || ((uintptr_t)v % 8)) return RG_ERR_ARG;
-        const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);
-        if (precision == 0) k_mha_fwd_bf16<3><<<grid, BW * RG_WAVE, 0, st>>>(g);
-        else if (precision == 3) k_mha_fwd_bf16<2, true><<<grid, BW * RG_WAVE, 0, st>>>(g);
-        else k_mha_fwd_bf16<1><<<grid, BW * RG_WAVE, 0, st>>>(g);
+        // clouds of more than 128 tokens need two 4-wave workgroups per head anyway: eight waves share every K / V tile instead (k_mha_fwd_bf16)
+        // -- on launches of many rounds of workgroups only.  Measured (tools/mha_bench.py, profiles/r06_f_mha_wide.txt; us per launch, 4 -> 8 waves):
+        // 384 clouds of 330-460 tokens, f16 pair 439.7 -> 419.5, bf16x3 553.7 -> 515.3; 512 clouds of 560-640, bf16 572.9 -> 554.9 (inside the
+        // ModelNet forward 547 -> 464); but 128 clouds of 230-360 (2048 eight-wave workgroups, four rounds on 256 CUs x 2) 93.9 -> 110.8.
+        if (MHA_WIDE && max_len > BW * TQ && (long long)rg_cdiv(max_len, BW8 * TQ) * n_heads * n_clouds >= 4096) {
+            const dim3 grid(rg_cdiv(max_len, BW8 * TQ), n_heads, n_clouds);
+            if (precision == 0) k_mha_fwd_bf16<3, false, BW8><<<grid, BW8 * RG_WAVE, 0, st>>>(g);
+            else if (precision == 3) k_mha_fwd_bf16<2, true, BW8><<<grid, BW8 * RG_WAVE, 0, st>>>(g);
+            else k_mha_fwd_bf16<1, false, BW8><<<grid, BW8 * RG_WAVE, 0, st>>>(g);
+        } else {
+            const dim3 grid(rg_cdiv(max_len, BW * TQ), n_heads, n_clouds);
+            if (precision == 0) k_mha_fwd_bf16<3><<<grid, BW * RG_WAVE, 0, st>>>(g);
+            else if (precision == 3) k_mha_fwd_bf16<2, true><<<grid, BW * RG_WAVE, 0, st>>>(g);
+            else k_mha_fwd_bf16<1><<<grid, BW * RG_WAVE, 0, st>>>(g);
+        }
     }
     RG_RETURN_IF_LAUNCH_FAILED();
     return RG_OK;

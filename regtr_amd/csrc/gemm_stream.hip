@@ -75,8 +75,15 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 
     extern __shared__ __align__(16) unsigned char Ws[];          // [3][NB][K] bf16, chunk-swizzled | double2 red[SG_WAVES][NB]
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int N = g.N, n0 = blockIdx.y * NB;
-    const int m0 = blockIdx.x * SG_ROWS, r0 = m0 + 32 * wave;     // the wave's strip
+    // Workgroup -> (row tile, column block), round 6: a 1-D launch in which the column blocks of ONE 256-row tile are consecutive workgroups of
+    // ONE XCD (workgroup id -> XCD id % 8): the tile's A rows are fetched from HBM once and served to the other column blocks by that XCD's L2.
+    // (Until round 5 the launch was (row tiles, column blocks) with the row tiles fastest: every column block re-read A from HBM a whole pass
+    //  later, which kept wide outputs off this kernel -- N <= 256 and at most two column blocks.)
+    const int ncol = g.N / NB;
+    const int wg_k = (int)(blockIdx.x >> 3), row_tile = (wg_k / ncol) * 8 + (int)(blockIdx.x & 7u);
+    if (row_tile * SG_ROWS >= g.M) return;                        // (the whole workgroup, before any barrier)
+    const int N = g.N, n0 = (wg_k % ncol) * NB;
+    const int m0 = row_tile * SG_ROWS, r0 = m0 + 32 * wave;       // the wave's strip
     const int row = r0 + l31;
     const bool row_ok = row < g.M;
 #ifdef SG_PROF
@@ -97,7 +104,7 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 
             raw[ks][1] = *(const float4*)(ap + 16 * ks + 4);
         }
     }
-    const int4 ti = g.tile_info[blockIdx.x];
+    const int4 ti = g.tile_info[row_tile];
     {
         // the weight planes by LDS-DMA (global_load_lds_dwordx4: 64 sixteen-byte pieces per instruction, no staging registers, every
         // instruction of the workgroup in flight at once behind the A loads).  A DMA fills LDS lane-linearly, so lane i of DMA q is slot
@@ -206,7 +213,7 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 
             double2 a = red[t];
 #pragma unroll
             for (int w = 1; w < SG_WAVES; w++) { const double2 b = red[w * NB + t]; a.x += b.x; a.y += b.y; }
-            g.stat_partial[(size_t)(blockIdx.x + sg) * N + n0 + t] = a;
+            g.stat_partial[(size_t)(row_tile + sg) * N + n0 + t] = a;
         }
         if (sg < s_hi) __syncthreads();                          // red is reused by the next cloud
     }
@@ -228,17 +235,18 @@ __global__ void __launch_bounds__(SG_WAVES* RG_WAVE, (KT <= 4 || NT <= 2) ? 4 : 
     SG_STAMP();
     __builtin_amdgcn_s_waitcnt(0);
     SG_STAMP();
-    if (lane == 0 && (blockIdx.x == 700 || blockIdx.x == 1500) && blockIdx.y == 0 && (wave == 0 || wave == 5))
-        printf("gemm_strip KT %d NT %d wg %d wave %d: loads+Wcopy %lld barrier %lld split %lld mfma %lld stats %lld store-issue %lld drain %lld total %lld\n", KT, NT, (int)blockIdx.x, wave,
+    if (lane == 0 && (row_tile == 700 || row_tile == 1500) && n0 == 0 && (wave == 0 || wave == 5))
+        printf("gemm_strip KT %d NT %d row tile %d wave %d: loads+Wcopy %lld barrier %lld split %lld mfma %lld stats %lld store-issue %lld drain %lld total %lld\n", KT, NT, row_tile, wave,
                pt[1] - pt[0], pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5], pt[7] - pt[6], pt[7] - pt[0]);
 #endif
 }
 
-// columns per workgroup column (32, 64 or 128): all of N when N <= 128 and planes + reduction buffer fit 64 KB of LDS, else half
+// columns per workgroup column: the widest of 128 / 64 / 32 that divides N and whose weight planes + reduction buffer fit 64 KB of LDS (two
+// workgroups per CU, four for the small ones)
 int sg_cols_per_wg(int N, int K)
 {
-    for (int nb = N; nb >= N / 2 && nb >= 32; nb /= 2)
-        if ((nb == 32 || nb == 64 || nb == 128) && N % nb == 0 && (size_t)nb * K * 6 + (size_t)SG_WAVES * nb * 16 <= 64 * 1024) return nb;
+    for (int nb = 128; nb >= 32; nb /= 2)
+        if (nb <= N && N % nb == 0 && (size_t)nb * K * 6 + (size_t)SG_WAVES * nb * 16 <= 64 * 1024) return nb;
     return 0;
 }
 
@@ -246,10 +254,10 @@ int sg_cols_per_wg(int N, int K)
 
 extern "C" {
 
-// 1 when regtr_gemm_stream serves the shape: K in {32, 64, 128}, N a multiple of 32 up to 256
+// 1 when regtr_gemm_stream serves the shape: K in {32, 64, 128}, N a multiple of 32 up to 512
 int regtr_gemm_stream_supported(int M, int N, int K)
 {
-    return (M >= 0 && (K == 32 || K == 64 || K == 128) && N >= 32 && N <= 256 && N % 32 == 0 && sg_cols_per_wg(N, K) > 0) ? 1 : 0;
+    return (M >= 0 && (K == 32 || K == 64 || K == 128) && N >= 32 && N <= 512 && N % 32 == 0 && sg_cols_per_wg(N, K) > 0) ? 1 : 0;
 }
 
 // rows per workgroup = statistics tile = the `rows` of the tile_info table (regtr_tile_segments) and of regtr_instnorm_finalize_tiles
@@ -277,7 +285,9 @@ int regtr_gemm_stream(const float* A, int lda, const void* planes, float* C, int
     const int NB = sg_cols_per_wg(N, K);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)3 * NB * K * 2 + (size_t)SG_WAVES * NB * 16;
-    const dim3 grid(rg_cdiv(M, SG_ROWS), N / NB);
+    const long long n_wg = (long long)rg_cdiv(rg_cdiv(M, SG_ROWS), 8) * 8 * (N / NB);     // (row tiles padded to the 8 XCDs) x column blocks
+    if (n_wg > 0x7fffffffLL) return RG_ERR_ARG;
+    const dim3 grid((unsigned)n_wg);
 #define SG_L3(KT_, NT_) do { if (a_stats) k_gemm_strip<KT_, NT_, (KT_ <= 4)><<<grid, SG_WAVES * RG_WAVE, lds, st>>>(g); \
                              else k_gemm_strip<KT_, NT_, false><<<grid, SG_WAVES * RG_WAVE, lds, st>>>(g); } while (0)
 #define SG_L2(KT_) do { if (NB == 32) SG_L3(KT_, 1); else if (NB == 64) SG_L3(KT_, 2); else SG_L3(KT_, 4); } while (0)
