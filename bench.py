@@ -574,7 +574,7 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
         warm, _ = step()
     if dist and warm is not None:
         # a warm-up pass ends like a timed one, with the pose gather: the FIRST all_gather_into_tensor of a process builds RCCL's channels and
-        # loads its kernels -- ~80 ms measured at world 1 (tools/torchrun_ab.sh: 87.7 vs 78.0 ms per step over 8 steps), which a plain
+        # loads its kernels -- ~80 ms measured at world 1 (round 5 A/B, profiles/r05_z_dist_stream.txt: 87.7 vs 78.0 ms per step over 8 steps), which a plain
         # `python bench.py` (no process group) never pays and a torchrun launch would otherwise pay inside the timed region
         gather(warm)
     sync()

@@ -54,7 +54,7 @@ extern "C" {
  * regtr_kpconv_gather, regtr_instnorm_apply, regtr_mha_fwd, regtr_gemm_x3): a binding generated from another version of the header
  * would pass shifted arguments, so every binding must compare regtr_abi_version() with the REGTR_ABI_VERSION it was written against
  * before its first call (regtr_amd/_lib.py does).  Bumped on any signature change. */
-#define REGTR_ABI_VERSION 10
+#define REGTR_ABI_VERSION 11
 int regtr_abi_version(void);
 
 /* The STATUS WORD: an optional device int (zeroed by the caller, e.g. once per forward) that kernels OR bits into -- conditions that
@@ -78,7 +78,7 @@ int regtr_grid_subsample(const float* xyz, const int* seg_off, int n_clouds, int
 
 /* The same with a choice of output row order: row_order 0 = first appearance (above); 1 = the reference's own order, i.e.
  * the iteration order of the libstdc++ std::unordered_map<size_t, .> it fills in input order (grid_subsampling.cpp:48,58-59,85)
- * -- the parity mode (cfg.kpconv_ref_row_order); one thread per cloud replays the container (csrc/ref_order.h). */
+ * -- the parity mode (cfg.kpconv_ref_row_order); one thread per cloud replays the container (csrc/ref_umap.h). */
 size_t regtr_grid_subsample_ordered_ws_bytes(int n_cap, int n_clouds, int row_order);
 /* key_mode: which of the reference's two voxel rules.
  *   0  floor((p - origin) / dl), origin = floor(min corner * (1 / dl)) * dl, linear size_t key -- the CPU Preprocessor's
@@ -134,25 +134,8 @@ int regtr_nearest_in_radius(const float* q_xyz, const int* q_seg_off, int nq_cap
  * (< ns) entries of the first H columns of row q of nbr, 0, 1); a row without a valid entry gives NaN as in the reference. */
 int regtr_overlap_avgpool(const float* ov, int ns, const int* nbr, int ld_nbr, int nq, int H, float* out, void* stream);
 
-/* Parity mode (cfg.kpconv_ref_row_order): the same neighbour sets in the REFERENCE's row order -- nanoflann's KD-tree
- * visiting order passed through std::sort on the distance alone (neighbors.cpp:246-267, nanoflann.hpp:857-1003,1348-1412,
- * 1285-1287) -- so that rows truncated to K keep the very supports the reference keeps when distances tie.  One thread
- * builds the tree of one cloud, one thread answers one query (csrc/ref_order.h); a parity tool, not a throughput path.
- *   regtr_kdtree_build          tree of every cloud into ws (regtr_kdtree_ws_bytes)
- *   regtr_kdtree_radius_query   out_idx [nq_cap,K] (first K of each row, pad = Ns_total), out_count / out_max_count as in
- *                               regtr_radius_query; list_cap >= the largest in-ball count (rows with more are cut at
- *                               list_cap BEFORE sorting -- the caller re-runs with list_cap = *out_max_count);
- *                               scratch: regtr_kdtree_query_scratch_bytes(list_cap).
- *                               out_status (optional device int, zeroed by the caller): set to 1 if a query overflowed its
- *                               traversal stack (96 pending subtrees; rows then invalid). */
-size_t regtr_kdtree_ws_bytes(int ns_cap, int n_clouds);
-size_t regtr_kdtree_query_scratch_bytes(int list_cap);
-int regtr_kdtree_build(const float* s_xyz, const int* s_seg_off, int n_clouds, int ns_cap, void* ws, size_t ws_bytes,
-                       void* stream);
-int regtr_kdtree_radius_query(const float* q_xyz, const int* q_seg_off, int nq_cap, const float* s_xyz,
-                              const int* s_seg_off, int ns_cap, int n_clouds, float radius, int K, int list_cap,
-                              const void* tree_ws, size_t ws_bytes, void* scratch, size_t scratch_bytes, int* out_idx,
-                              int* out_count, int* out_max_count, int* out_status, void* stream);
+/* (Parity mode's neighbour tables in the reference's KD-tree / std::sort row order: include/regtr_hip_parity.h, libregtr_parity.so --
+ * since ABI 11 a library of its own, so that the product library holds no nanoflann-derived code.) */
 
 /* ---- KPConv encoder --------------------------------------------------------------------------------------- */
 

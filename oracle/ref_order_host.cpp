@@ -1,8 +1,9 @@
-// TEST INFRASTRUCTURE ONLY.  Compiles the product's reference-order emulation (regtr_amd/csrc/ref_order.h -- the very
+// TEST INFRASTRUCTURE ONLY.  Compiles the product's reference-order emulation (regtr_amd/csrc/ref_umap.h + ref_kdtree.h -- the very
 // functions the HIP parity-mode kernels run, one thread per cloud / query) for the HOST, next to the real things they
 // emulate: libstdc++'s std::unordered_map iteration and std::sort.  tests/test_ref_order.py compares the two, and the
 // emulated neighbour tables against the unmodified reference C++ (oracle/_ref).  Nothing in the product loads this.
-#include "../regtr_amd/csrc/ref_order.h"
+#include "../regtr_amd/csrc/ref_umap.h"
+#include "../regtr_amd/csrc/ref_kdtree.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>

@@ -39,7 +39,16 @@ class EncoderLevel(_c.Structure):
 
 
 # name -> (restype, argtypes); mirrors include/regtr_hip.h one to one
-ABI_VERSION = 10         # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+ABI_VERSION = 11         # REGTR_ABI_VERSION of the include/regtr_hip.h these signatures mirror
+
+# libregtr_parity.so (include/regtr_hip_parity.h): parity mode's KD-tree-order neighbour search, loaded on first use (parity_lib)
+PARITY_SIGNATURES = {
+    'regtr_parity_abi_version': (_I, []),
+    'regtr_kdtree_ws_bytes': (_Z, [_I, _I]),
+    'regtr_kdtree_query_scratch_bytes': (_Z, [_I]),
+    'regtr_kdtree_build': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
+    'regtr_kdtree_radius_query': (_I, [_P, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _Z, _P, _P, _P, _P, _P]),
+}
 
 SIGNATURES = {
     'regtr_abi_version': (_I, []),
@@ -47,10 +56,6 @@ SIGNATURES = {
     'regtr_grid_subsample': (_I, [_P, _P, _I, _I, _F, _P, _P, _P, _Z, _P]),
     'regtr_grid_subsample_ordered_ws_bytes': (_Z, [_I, _I, _I]),
     'regtr_grid_subsample_ordered': (_I, [_P, _P, _I, _I, _F, _I, _I, _I, _P, _P, _P, _Z, _P]),
-    'regtr_kdtree_ws_bytes': (_Z, [_I, _I]),
-    'regtr_kdtree_query_scratch_bytes': (_Z, [_I]),
-    'regtr_kdtree_build': (_I, [_P, _P, _I, _I, _P, _Z, _P]),
-    'regtr_kdtree_radius_query': (_I, [_P, _P, _I, _P, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _Z, _P, _P, _P, _P, _P]),
     'regtr_cellgrid_ws_bytes': (_Z, [_I, _I]),
     'regtr_cellgrid_build': (_I, [_P, _P, _I, _I, _F, _P, _Z, _P]),
     'regtr_radius_query': (_I, [_P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _Z, _P, _P, _P, _P]),
@@ -146,6 +151,30 @@ def _load():
             raise RuntimeError(f'{LIB_PATH} implements C-ABI version {got}, this binding was written for {ABI_VERSION}: rebuild with '
                                '`python -m regtr_amd.build --force`')
     return _lib
+
+
+_parity = None
+PARITY_LIB_PATH = os.path.join(_HERE, 'libregtr_parity.so')
+
+
+def parity_lib():
+    """libregtr_parity.so, loaded when parity mode (cfg.kpconv_ref_row_order / cpp_wrappers.reference_order) first asks for a KD-tree-order
+    neighbour table; the default path never does.  Missing library -> RuntimeError (there is no fallback)."""
+    global _parity
+    if _parity is None:
+        with _load_lock:
+            if _parity is None:
+                if not os.path.exists(PARITY_LIB_PATH):
+                    raise RuntimeError(f'{PARITY_LIB_PATH} is missing: build it with `python -m regtr_amd.build` (parity mode only)')
+                lib_ = ctypes.PyDLL(PARITY_LIB_PATH)
+                for name, (res, args) in PARITY_SIGNATURES.items():
+                    fn = getattr(lib_, name)
+                    fn.restype, fn.argtypes = res, args
+                if lib_.regtr_parity_abi_version() != ABI_VERSION:
+                    raise RuntimeError(f'{PARITY_LIB_PATH} was built against C-ABI version {lib_.regtr_parity_abi_version()}, this binding is {ABI_VERSION}: '
+                                       'rebuild with `python -m regtr_amd.build --force`')
+                _parity = lib_
+    return _parity
 
 
 def check(status, what):

@@ -9,12 +9,16 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libregtr_hip.so')
+# the parity-mode neighbour search (include/regtr_hip_parity.h): nanoflann's KD-tree order + std::sort replayed on the GPU -- a checking mode's
+# library of its own, so that the product library holds no nanoflann-derived code (THIRD_PARTY_NOTICES.md)
+PARITY_LIB = os.path.join(HERE, 'libregtr_parity.so')
+PARITY_SOURCES = ['ref_order.hip']
 # development only: REGTR_VARIANT=name REGTR_VARIANT_FLAGS='-DX=1' builds libregtr_hip.name.so for A/B kernel experiments
 VARIANT = os.environ.get('REGTR_VARIANT', '')
 VARIANT_FLAGS = os.environ.get('REGTR_VARIANT_FLAGS', '').split()
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 ARCH = 'gfx950'
-SOURCES = ['preprocess.hip', 'ref_order.hip', 'kpconv.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_stream.hip', 'block_tail.hip', 'norm.hip', 'attention.hip', 'cross_encoder.hip', 'encoder.hip', 'procrustes.hip']
+SOURCES = ['preprocess.hip', 'kpconv.hip', 'gemm.hip', 'gemm_x3.hip', 'gemm_stream.hip', 'block_tail.hip', 'norm.hip', 'attention.hip', 'cross_encoder.hip', 'encoder.hip', 'procrustes.hip']
 # bit-level parity of the float32 distance / voxel arithmetic with the reference's SSE2 build needs no contraction
 # kpconv.hip: SLP-packed f32 VALU (v_pk_*) beside MFMAs costs more than it saves and blocks v_add_f32_dpp fusion
 EXTRA = {'preprocess.hip': ['-ffp-contract=off'], 'ref_order.hip': ['-ffp-contract=off'], 'kpconv.hip': ['-fno-slp-vectorize']}
@@ -89,9 +93,32 @@ def build(force=False, verbose=False, variant=None, variant_flags=None):
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
+    if not VARIANT:
+        build_parity(force, verbose)
     if not VARIANT and os.path.isdir(os.path.join(os.path.dirname(HERE), '.git')):
         write_build_info()
     return LIB
+
+
+def build_parity(force=False, verbose=False):
+    """libregtr_parity.so from csrc/ref_order.hip (regtr_amd/_lib.py: parity_lib; loaded only when parity mode asks for KD-tree tables)."""
+    objdir = os.path.join(HERE, 'build', 'parity')
+    os.makedirs(objdir, exist_ok=True)
+    inc = os.path.join(os.path.dirname(HERE), 'include')
+    deps = ([os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith('.h')])
+    objs, changed = [], False
+    for src in PARITY_SOURCES:
+        s, o = os.path.join(CSRC, src), os.path.join(objdir, src.replace('.hip', '.o'))
+        if force or _stale(o, [s] + deps):
+            cmd = [HIPCC] + COMMON + EXTRA.get(src, []) + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+            changed = True
+        objs.append(o)
+    if force or changed or not os.path.exists(PARITY_LIB):
+        subprocess.check_call([HIPCC, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', PARITY_LIB] + objs)
+    return PARITY_LIB
 
 
 def build_experimental(force=False, verbose=False):
@@ -101,5 +128,6 @@ def build_experimental(force=False, verbose=False):
 
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    print(build_parity(force='--force' in sys.argv, verbose=True))
     if '--experimental' in sys.argv:
         print(build_experimental(force='--force' in sys.argv, verbose=True))

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(MO_WAVES* RG_WAVE, 4) k_moments(const float* _
     // wave and chunk of the cloud loads the same ones and adds them in the same order: one value per cloud and channel).  Round 5: it
     // used to be the cloud's FIRST row -- on a real 3DMatch fragment that row can be an outlier (an isolated point whose kernel-point sums
     // are a tenth of the typical ones), the pivot then sits ~6 sigma from the mean and the statistics lose a factor ~36: 3e-5 on the encoder
-    // output of one cloud in nine (tools/real_diag.py), against 2e-6 from a pivot near the mean.  k_tail_prepare adds the pivot back.
+    // output of one cloud in nine (profiles/r05_real_diag.txt), against 2e-6 from a pivot near the mean.  k_tail_prepare adds the pivot back.
     float pv[KC];
     {
         const int r0 = seg_off[cloud];

@@ -19,7 +19,7 @@
 //   Distance and voxel arithmetic use explicit round-to-nearest intrinsics (no FMA contraction) so the
 //   float32 results match the reference's SSE2 arithmetic bit for bit.
 #include "common.h"
-#include "ref_order.h"
+#include "ref_umap.h"
 #include <limits.h>
 
 namespace {
@@ -447,7 +447,7 @@ __global__ void __launch_bounds__(256) k_barycentres(const float* __restrict__ x
     out_xyz[3 * (size_t)j + 2] = __fmul_rn(sz, w);
 }
 
-// ---- reference row order (parity mode, ref_order.h): the voxel keys in first-appearance order, then one thread per cloud
+// ---- reference row order (parity mode, ref_umap.h): the voxel keys in first-appearance order, then one thread per cloud
 // replays the libstdc++ unordered_map the reference iterates (grid_subsampling.cpp:48,58-59,85) ----
 __global__ void __launch_bounds__(256) k_rank_keys(const int* __restrict__ n_ptr, const int* __restrict__ slot_of,
                                                    const int* __restrict__ first, const uint64_t* __restrict__ scan_out,

@@ -1,4 +1,4 @@
-// Reference-order parity mode (cfg.kpconv_ref_row_order): the two IMPLEMENTATION-DEFINED orders of the reference's CPU
+// Reference-order parity mode (cfg.kpconv_ref_row_order), part 2 (part 1: ref_umap.h): the two IMPLEMENTATION-DEFINED orders of the reference's CPU
 // preprocessing ops, reproduced so that the product can be compared with the reference's own outputs row for row.
 //
 //   1. grid subsample row order = iteration order of the libstdc++ std::unordered_map<size_t, SampledData> the reference
@@ -16,7 +16,7 @@
 // The default (fast) path never touches this file's functions.
 // THIRD-PARTY NOTICE.  The KD-tree functions of section 2 (rg_kd_minmax, rg_kd_plane_split, rg_kd_build, rg_kd_radius_search and
 // their helpers) restate algorithms of nanoflann 1.3.0 (divideTree / middleSplit_ / planeSplit / searchLevel, nanoflann.hpp:857-1003,
-// 1348-1412) closely enough to reproduce its visiting order; they are compiled into libregtr_hip.so (parity mode only).  nanoflann is
+// 1348-1412) closely enough to reproduce its visiting order; they are compiled into libregtr_parity.so ONLY (include/regtr_hip_parity.h; the product library libregtr_hip.so does not contain them).  nanoflann is
 // distributed under the BSD license, whose notice is retained here and in THIRD_PARTY_NOTICES.md as its conditions require:
 //
 //   Software License Agreement (BSD License)
@@ -49,88 +49,6 @@
 #else
 #define RG_HD inline
 #endif
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 1. std::unordered_map<size_t, T> iteration order
-// ---------------------------------------------------------------------------------------------------------------------
-// Bucket-count schedule of libstdc++'s _Prime_rehash_policy (max_load_factor 1, growth factor 2, __prime_list lookup)
-// for a map that starts empty: inserting the element that makes size() == at_size first rehashes to `buckets`.
-// Generated from the real container (tests/test_ref_order.py re-checks it against the toolchain's libstdc++).
-struct RgUmapGrowth { uint32_t at_size, buckets; };
-#define RG_UMAP_GROWTH_LEN 25
-#define RG_UMAP_GROWTH_TABLE                                                                                             \
-    {{1u, 13u}, {14u, 29u}, {30u, 59u}, {60u, 127u}, {128u, 257u}, {258u, 541u}, {542u, 1109u}, {1110u, 2357u},          \
-     {2358u, 5087u}, {5088u, 10273u}, {10274u, 20753u}, {20754u, 42043u}, {42044u, 85229u}, {85230u, 172933u},           \
-     {172934u, 351061u}, {351062u, 712697u}, {712698u, 1447153u}, {1447154u, 2938679u}, {2938680u, 5967347u},            \
-     {5967348u, 12117689u}, {12117690u, 24607243u}, {24607244u, 49969847u}, {49969848u, 101473717u},                     \
-     {101473718u, 206062531u}, {206062532u, 418451333u}}
-
-// bucket count of a map holding m elements (m >= 1); also an upper bound for every smaller map
-RG_HD uint32_t rg_umap_bucket_count(uint32_t m)
-{
-    const RgUmapGrowth g[RG_UMAP_GROWTH_LEN] = RG_UMAP_GROWTH_TABLE;
-    uint32_t b = 1;
-    for (int i = 0; i < RG_UMAP_GROWTH_LEN; i++)
-        if (m >= g[i].at_size) b = g[i].buckets;
-    return b;
-}
-
-// Where cloud c's `before` array starts inside one shared scratch array, given that the clouds before it hold `base`
-// elements in total: rg_umap_bucket_count(m) <= 2.16 m + 13 (worst ratio of the schedule: 5087 buckets at 2358 elements).
-RG_HD size_t rg_umap_before_offset(size_t base, size_t c) { return base * 11 / 5 + 16 * c; }
-
-// keys[0 .. m): the distinct keys in insertion order (hash = identity, bucket = key % bucket_count).
-// next[m + 1], before[rg_umap_bucket_count(m)]: scratch.  order[m]: order[p] = insertion index of the p-th element
-// a range-for over the map visits.
-//   _M_insert_bucket_begin (hashtable.h): a node goes to the FRONT of its bucket; a bucket that was empty goes to the front
-//   of the whole list (the bucket then "begins" at the before-begin sentinel).  _M_rehash_aux(unique) relinks the nodes in
-//   their current list order by the same rule.
-RG_HD void rg_umap_iteration_order(const uint64_t* keys, int m, int* next, int* before, int* order)
-{
-    const RgUmapGrowth g[RG_UMAP_GROWTH_LEN] = RG_UMAP_GROWTH_TABLE;
-    const int BB = m, NIL = -1, EMPTY = -2;      // BB: the before-begin sentinel "node"
-    uint64_t nb = 1;
-    int gi = 0;
-    next[BB] = NIL;
-    before[0] = EMPTY;
-    for (int e = 0; e < m; e++) {
-        if (gi < RG_UMAP_GROWTH_LEN && (uint32_t)(e + 1) == g[gi].at_size) {      // _M_rehash_aux, unique keys
-            nb = g[gi].buckets;
-            gi++;
-            for (uint64_t b = 0; b < nb; b++) before[b] = EMPTY;
-            int p = next[BB];
-            next[BB] = NIL;
-            uint64_t bbegin_bkt = 0;
-            while (p != NIL) {
-                const int nx = next[p];
-                const uint64_t bkt = keys[p] % nb;
-                if (before[bkt] == EMPTY) {
-                    next[p] = next[BB];
-                    next[BB] = p;
-                    before[bkt] = BB;
-                    if (next[p] != NIL) before[bbegin_bkt] = p;
-                    bbegin_bkt = bkt;
-                } else {
-                    next[p] = next[before[bkt]];
-                    next[before[bkt]] = p;
-                }
-                p = nx;
-            }
-        }
-        const uint64_t bkt = keys[e] % nb;                                        // _M_insert_bucket_begin
-        if (before[bkt] != EMPTY) {
-            next[e] = next[before[bkt]];
-            next[before[bkt]] = e;
-        } else {
-            next[e] = next[BB];
-            next[BB] = e;
-            if (next[e] != NIL) before[keys[next[e]] % nb] = e;
-            before[bkt] = BB;
-        }
-    }
-    int p = next[BB];
-    for (int i = 0; i < m; i++) { order[i] = p; p = next[p]; }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // 2a. std::sort(first, last, comp) of libstdc++ (stl_algo.h: __introsort_loop + __final_insertion_sort, threshold 16,
@@ -450,3 +368,4 @@ RG_HD int rg_kd_radius_search(const float* pts, const int* vind, const RgKdNode*
     rg_std_sort(list, m, stack);                                      // searchParams.sorted (neighbors.cpp:267)
     return n;
 }
+

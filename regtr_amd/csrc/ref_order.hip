@@ -2,13 +2,15 @@
 // cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-332) returns rows in nanoflann's KD-tree visiting order passed
 // through std::sort on the distance alone, then kpconv.py:255-256 keeps the first neighborhood_limits columns -- so on
 // clouds with exactly equidistant supports (the 6 mm lattice of the 3DMatch fragments) WHICH supports a truncated row
-// keeps is decided by that tree and that sort.  These kernels replay both (ref_order.h: the same serial functions
+// keeps is decided by that tree and that sort.  These kernels replay both (ref_kdtree.h: the same serial functions
 // tests/test_ref_order.py checks on the host against the unmodified reference C++): one thread builds the tree of one
-// cloud, one thread answers one query.  Parity tool, not a throughput path -- the default tables come from
+// cloud, one thread answers one query.  Built into libregtr_parity.so (include/regtr_hip_parity.h), NOT into the product library.
+// Parity tool, not a throughput path -- the default tables come from
 // preprocess.hip (cell grid, one wave per query, ascending (d2, index)) and are identical as SETS except on rows whose
 // K-th and (K+1)-th distances tie.
 #include "common.h"
-#include "ref_order.h"
+#include "regtr_hip_parity.h"      // this library's own C ABI: definitions checked against their declarations
+#include "ref_kdtree.h"
 
 namespace {
 
@@ -79,6 +81,8 @@ k_kd_query(const float* __restrict__ q_xyz, const int* __restrict__ q_seg_off, c
 }  // namespace
 
 extern "C" {
+
+int regtr_parity_abi_version(void) { return REGTR_ABI_VERSION; }
 
 size_t regtr_kdtree_ws_bytes(int ns_cap, int n_clouds)
 {

@@ -75,11 +75,12 @@ class CellGrid:
 
 
 class KdTree:
-    """Parity mode (cfg.kpconv_ref_row_order): nanoflann-order neighbour tables (csrc/ref_order.hip).  Unlike CellGrid this
-    synchronises with the host (the list capacity must cover the largest in-ball count, known only after a first pass)."""
+    """Parity mode (cfg.kpconv_ref_row_order): nanoflann-order neighbour tables (csrc/ref_order.hip, in libregtr_parity.so: include/
+    regtr_hip_parity.h).  Unlike CellGrid this synchronises with the host (the list capacity must cover the largest in-ball count, known only
+    after a first pass)."""
 
     def __init__(self, s_xyz, s_seg_off, ns_cap):
-        L = _lib.lib()
+        L = _lib.parity_lib()
         self.n_clouds = s_seg_off.numel() - 1
         self.s_xyz, self.s_seg_off, self.ns_cap = s_xyz, s_seg_off, int(ns_cap)
         self.nbytes = L.regtr_kdtree_ws_bytes(self.ns_cap, self.n_clouds)
@@ -89,7 +90,7 @@ class KdTree:
 
     def query(self, q_xyz, q_seg_off, nq_cap, radius, K, list_cap=128):
         """-> (idx (nq_cap, K) i32 in the reference's row order, max in-ball count (host int))."""
-        L = _lib.lib()
+        L = _lib.parity_lib()
         dev = q_xyz.device
         idx = torch.empty((max(nq_cap, 1), K), dtype=torch.int32, device=dev)
         while True:

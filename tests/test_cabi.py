@@ -41,6 +41,14 @@ def test_library_exports_every_declared_symbol():
         assert sorted(set(re.findall(r'\bT (regtr_\w+)', out))) == sorted(names + exp)
     txt = open(os.path.join(ROOT, 'include', 'regtr_hip.h')).read()
     assert int(re.search(r'#define REGTR_ABI_VERSION (\d+)', txt).group(1)) == _lib.ABI_VERSION == lib.regtr_abi_version()
+    # the parity-mode library (include/regtr_hip_parity.h): its own header, its own exports, the same ABI version -- and no KD-tree symbol
+    # in the product library (the nanoflann-derived code of csrc/ref_kdtree.h ships in libregtr_parity.so only)
+    par = _header_symbols('regtr_hip_parity.h')
+    assert sorted(_lib.PARITY_SIGNATURES) == par and not set(par) & set(names) and not [n for n in names if 'kdtree' in n]
+    pl = _lib.parity_lib()
+    assert pl.regtr_parity_abi_version() == _lib.ABI_VERSION
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.PARITY_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert sorted(set(re.findall(r'\bT (regtr_\w+)', out))) == par
 
 
 def test_stray_env_switch_does_not_reroute():

@@ -1,4 +1,4 @@
-"""CPU: the reference-order emulation the parity-mode HIP kernels run (regtr_amd/csrc/ref_order.h, compiled for the host
+"""CPU: the reference-order emulation the parity-mode HIP kernels run (regtr_amd/csrc/ref_umap.h + ref_kdtree.h, compiled for the host
 by oracle/Makefile) against the real things: libstdc++'s std::unordered_map iteration order and std::sort, and the
 unmodified reference C++ (nanoflann KD-tree visiting order + std::sort) through oracle/_ref."""
 import ctypes

@@ -35,7 +35,7 @@ def main():
         f.write('\n'.join(tail) + '\n')
     with open(os.path.join(dst, f'{a.tag}_e2e_harness.txt'), 'w') as out:
         out.write('# tools/evidence.sh: test.py --benchmark 3DLoMatch --synthetic 1781 (files -> loader -> H2D -> forward -> pose gather -> est.log)\n')
-        for name in ('e2e_build', 'e2e_npy', 'e2e_pth', 'e2e_thread'):
+        for name in ('e2e_build', 'e2e_npy', 'e2e_pth', 'e2e_npy_batch64', 'e2e_npy_cold', 'e2e_thread'):
             p = os.path.join(src, name + '.log')
             if os.path.exists(p):
                 lines = [l for l in open(p).read().splitlines() if 'End to end' in l or 'loader:' in l or 'materialised' in l]
