@@ -900,7 +900,14 @@ def main():
                     'compared with `value` as a speed-up of one over the other'}
             except (OSError, KeyError, ValueError):
                 pass
-        print(json.dumps(res))
+        # the JSON line is the LAST line of stdout: RCCL writes its version banner through C stdio, which (into a pipe or a file) is flushed at
+        # exit and would land behind a Python print -- push it out first
+        try:
+            import ctypes
+            sys.stdout.flush(); ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(res), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(KS * RG_WAVE) __attribute__((amdgpu_waves_per_
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BW = 4;                 // waves (32-query tiles) per workgroup; clouds of more than 128 tokens: BW8 = 8 (round 6, below)
 constexpr int BW8 = 8;
 constexpr int BROW = 64;              // bytes per LDS row
@@ -236,7 +237,8 @@ __device__ __forceinline__ void bf_split2(float a, float b, unsigned (&p)[NP])
         static_assert(NP == 2, "the f16 pair has two planes");
         p[0] = f16_pack(a, b);
         const f16x2v h = __builtin_bit_cast(f16x2v, p[0]);
-        p[1] = f16_pack((a - (float)h.x) * MHA_F16_SCALE, (b - (float)h.y) * MHA_F16_SCALE);
+        const f32x2 r = (f32x2{a, b} - f32x2{(float)h.x, (float)h.y}) * f32x2{MHA_F16_SCALE, MHA_F16_SCALE};      // (v_pk_add_f32 + v_pk_mul_f32)
+        p[1] = f16_pack(r.x, r.y);
         return;
     }
     p[0] = bf_pack(a, b);
@@ -453,9 +455,16 @@ __global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
                 else sc = bf_mma<NP>(kf, qf[ks], sc);
                 MHA_PRIO(0);
             }
+            // (PAIRS, round 6: written on two-element vectors so that hipcc emits the packed-f32 instructions -- v_pk_fma_f32 / v_pk_add_f32 do two
+            //  lanes' worth of elements per issue slot.  The scalar form compiled to 17 v_sub + 17 v_add (+ 16 v_fma in the f16 pair form) per key
+            //  tile next to 17 quarter-rate v_exp: the softmax is what bounds this kernel at head dimension 32.)
             if constexpr (F16) {
+                const f32x2 lsc = {1.0f / MHA_F16_SCALE, 1.0f / MHA_F16_SCALE};
 #pragma unroll
-                for (int r = 0; r < 16; r++) sc[r] += sc_lo[r] * (1.0f / MHA_F16_SCALE);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = f32x2{sc_lo[r], sc_lo[r + 1]} * lsc + f32x2{sc[r], sc[r + 1]};
+                    sc[r] = v.x; sc[r + 1] = v.y;
+                }
             }
             MHA_STAMP(2);
             if (!MHA_OPT_MASK || kt + TK > nk) {       // (workgroup-uniform: only the last tile of a cloud has keys past the end)
@@ -469,14 +478,17 @@ __global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
             mx = mha_max_halves(mx);
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            float psum = 0.f;
             float pr[16];
+            f32x2 ps2 = {0.f, 0.f};
+            const f32x2 mm = {m_new, m_new};
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new);
-                psum += pr[r];
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 d = f32x2{sc[r], sc[r + 1]} - mm;
+                pr[r] = __builtin_amdgcn_exp2f(d.x);
+                pr[r + 1] = __builtin_amdgcn_exp2f(d.y);
+                ps2 += f32x2{pr[r], pr[r + 1]};
             }
-            psum = mha_sum_halves(psum);
+            float psum = mha_sum_halves(ps2.x + ps2.y);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
