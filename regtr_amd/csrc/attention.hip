@@ -214,6 +214,9 @@ constexpr float MHA_F16_SCALE = 2048.f;
 #ifndef MHA_WAVES_ATTR
 #define MHA_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(3)))
 #endif
+#ifndef MHA_PACKED
+#define MHA_PACKED 0                  // softmax / pair-split arithmetic on two-element vectors (v_pk_*_f32): measured SLOWER (below); A/B: -DMHA_PACKED=1
+#endif
 #ifndef MHA_WIDE
 #define MHA_WIDE 1                    // 8-wave workgroups for clouds of more than 128 tokens (A/B: -DMHA_WIDE=0)
 #endif
@@ -237,8 +240,12 @@ __device__ __forceinline__ void bf_split2(float a, float b, unsigned (&p)[NP])
         static_assert(NP == 2, "the f16 pair has two planes");
         p[0] = f16_pack(a, b);
         const f16x2v h = __builtin_bit_cast(f16x2v, p[0]);
+#if MHA_PACKED
         const f32x2 r = (f32x2{a, b} - f32x2{(float)h.x, (float)h.y}) * f32x2{MHA_F16_SCALE, MHA_F16_SCALE};      // (v_pk_add_f32 + v_pk_mul_f32)
         p[1] = f16_pack(r.x, r.y);
+#else
+        p[1] = f16_pack((a - (float)h.x) * MHA_F16_SCALE, (b - (float)h.y) * MHA_F16_SCALE);
+#endif
         return;
     }
     p[0] = bf_pack(a, b);
@@ -459,12 +466,17 @@ __global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
             //  lanes' worth of elements per issue slot.  The scalar form compiled to 17 v_sub + 17 v_add (+ 16 v_fma in the f16 pair form) per key
             //  tile next to 17 quarter-rate v_exp: the softmax is what bounds this kernel at head dimension 32.)
             if constexpr (F16) {
+#if MHA_PACKED
                 const f32x2 lsc = {1.0f / MHA_F16_SCALE, 1.0f / MHA_F16_SCALE};
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2 v = f32x2{sc_lo[r], sc_lo[r + 1]} * lsc + f32x2{sc[r], sc[r + 1]};
                     sc[r] = v.x; sc[r + 1] = v.y;
                 }
+#else
+#pragma unroll
+                for (int r = 0; r < 16; r++) sc[r] += sc_lo[r] * (1.0f / MHA_F16_SCALE);
+#endif
             }
             MHA_STAMP(2);
             if (!MHA_OPT_MASK || kt + TK > nk) {       // (workgroup-uniform: only the last tile of a cloud has keys past the end)
@@ -479,6 +491,7 @@ __global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float pr[16];
+#if MHA_PACKED
             f32x2 ps2 = {0.f, 0.f};
             const f32x2 mm = {m_new, m_new};
 #pragma unroll
@@ -489,6 +502,12 @@ __global__ void __launch_bounds__(NW * RG_WAVE) MHA_WAVES_ATTR k_mha_fwd_bf16(Mh
                 ps2 += f32x2{pr[r], pr[r + 1]};
             }
             float psum = mha_sum_halves(ps2.x + ps2.y);
+#else
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { pr[r] = __builtin_amdgcn_exp2f(sc[r] - m_new); psum += pr[r]; }
+            psum = mha_sum_halves(psum);
+#endif
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
