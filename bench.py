@@ -35,8 +35,8 @@ MFMA_BF16_PEAK_TFS = 2500.0   # dense bf16 MFMA peak (same guide); the f32-input
 
 
 from regtr_amd.synthetic import synth_modelnet_pair, synth_pair  # noqa: E402  
-from regtr_amd.workload import (DEFAULT_PAIRS, REAL_PAIRS, REDUCED_TOL, build_workload, kpconv_algorithmic_bytes, parity_slots,  # noqa: E402,F401
-                                probe_head, real_pairs)
+from regtr_amd.workload import (DEFAULT_PAIRS, DEFAULT_REPLICAS, REAL_PAIRS, REDUCED_TOL, build_workload, kpconv_algorithmic_bytes, parity_slots,  # noqa: E402,F401
+                                probe_head, real_pairs, ReplicaRunner, replicate)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -264,7 +264,8 @@ def collect_pmc(args):
     if not shutil.which('rocprofv3'):
         sys.exit('bench.py --collect-pmc: rocprofv3 not found')
     work = tempfile.mkdtemp(prefix='regtr_pmc_', dir=os.environ.get('TMPDIR', '/tmp'))
-    inner = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--settle-s', '0', '--no-cpu-baseline', '--no-roofline', '--no-real',
+    inner = [sys.executable, os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--settle-s', '0', '--no-cpu-baseline', '--no-roofline', '--no-real', '--replicas', '1', '--head-init', 'uniform',      # (uniform head: no calibration forward among the counted ones)
+            
              '--parity-pairs', '0', '--no-strict-f32', '--points', str(args.points)] + (['--pairs', str(args.pairs)] if args.pairs else []) \
         + (['--shuffle'] if args.shuffle else [])
     vals = defaultdict(lambda: defaultdict(list))
@@ -326,22 +327,26 @@ def measure_real_fragments(args, dev, dtype, steps=8, parity_pairs=4):
     """`real_fragments_pairs_per_s` of the default line: BASELINE configs[2] on the three REAL 3DMatch pairs the reference ships (demo.py:26-49; red-kitchen,
     hotel_umd, home_at), replicated to the same pairs per forward under random rigid motions (workload.real_pairs), probe head -- 2 warm-up + `steps` timed
     forwards between device synchronisations, then the CPU-oracle gate on `parity_pairs` of them."""
-    cfg_r, model_r, pairs_r, batch_r = build_workload('3dmatch', args.pairs, args.points, False, 0, dev, dtype, real=True)
-    for _ in range(2):
-        out = model_r(dict(batch_r))
+    R = max(1, args.replicas)
+    n = R * args.pairs
+    cfg_r, model_r, pairs_r, batch_r = build_workload('3dmatch', n, args.points, False, 0, dev, dtype, real=True)
+    chunks_r = [(i * args.pairs, (i + 1) * args.pairs) for i in range(R)]
+    runner = ReplicaRunner(replicate(model_r, cfg_r, R, dev), batch_r, chunks_r, dev)
+    runner.run(2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(steps):
-        out = model_r(dict(batch_r))
+    outs = runner.run(steps)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
-    lv = [int(p.shape[0]) for p in model_r.preprocessor(list(batch_r['src_xyz']) + list(batch_r['tgt_xyz']))['points']]
-    info = {'value': args.pairs / dt, 'unit': 'pairs/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'pairs_per_step': args.pairs, 'level_points': lv,
+    out, pairs_r = outs[0], pairs_r[:args.pairs]
+    first = {k: v[:args.pairs] for k, v in batch_r.items()}
+    lv = [int(p.shape[0]) for p in model_r.preprocessor(list(first['src_xyz']) + list(first['tgt_xyz']))['points']]
+    info = {'value': n / dt, 'unit': 'pairs/s', 'ms_per_step': dt * 1e3, 'steps': steps, 'pairs_per_step': n, 'concurrent_forwards': R, 'level_points_per_forward': lv,
             'points_per_cloud': [int(np.mean([len(s) for s, _ in pairs_r])), int(np.mean([len(t) for _, t in pairs_r]))],
             'data': 'the three 3DMatch pairs the reference ships (tests/golden/3dmatch_*.npz), replicated under random rigid motions; head: linear probe'}
     if parity_pairs > 0:
         slots = parity_slots([len(a) + len(b) for a, b in pairs_r], parity_pairs)
         p = parity_check(cfg_r, model_r, pairs_r, out, slots)
         info['parity'] = {k: p[k] for k in ('ok', 'pose_max_abs', 'corr_max_abs', 'kabsch_cond_max', 'pairs_checked', 'keypoints_bit_exact', 'reason')}
-    del model_r, batch_r
+    del model_r, batch_r, runner, outs
     torch.cuda.empty_cache()
     return info['value'], info
 
@@ -534,7 +539,8 @@ def plan_pairs(args, rank, world, device):
         mine = shard_pairs(args.total_pairs, 0, emu) if emu else shard_pairs(args.total_pairs, rank, world)
         pair_ids = torch.tensor(mine, device=device, dtype=torch.int32)
     else:
-        pair_ids = torch.arange(per_fwd, device=device, dtype=torch.int32) + rank * per_fwd
+        R = max(1, getattr(args, 'replicas', 1) or 1)          # R concurrent forwards of per_fwd pairs each (workload.ReplicaRunner)
+        pair_ids = torch.arange(R * per_fwd, device=device, dtype=torch.int32) + rank * R * per_fwd
     n_local = int(pair_ids.numel())
     n_fwd = max(1, -(-n_local // per_fwd))
     base, extra = divmod(n_local, n_fwd)
@@ -542,7 +548,7 @@ def plan_pairs(args, rank, world, device):
     for i in range(n_fwd):
         hi = lo + base + (1 if i < extra else 0)
         chunks.append((lo, hi)); lo = hi
-    return lomatch, per_fwd, pair_ids, chunks, (n_local if emu else (args.total_pairs if lomatch else per_fwd * world))
+    return lomatch, per_fwd, pair_ids, chunks, (n_local if emu else (args.total_pairs if lomatch else n_local * world))
 
 
 def settle_device(step, budget_s, sync=None):
@@ -581,10 +587,13 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     if dist: dist.barrier()
     t0 = time.perf_counter()
     poses = extra = gathered = None
-    for _ in range(args.steps):
-        poses, extra = step()
-        if lomatch:
-            gathered = gather(poses)
+    if not lomatch and hasattr(step, 'many'):
+        poses, extra = step.many(args.steps)       # R host threads run their K forwards each without meeting in between (workload.ReplicaRunner)
+    else:
+        for _ in range(args.steps):
+            poses, extra = step()
+            if lomatch:
+                gathered = gather(poses)
     if not lomatch:
         gathered = gather(poses)
     sync()
@@ -600,9 +609,9 @@ def timed_passes(args, dist, lomatch, pair_ids, step, sync, device):
     return elapsed, gathered[0], gathered[1], extra, per_rank
 
 
-def count_ranks(all_ids, lomatch, per_fwd, world):
-    """Ranks whose poses arrived through the gather (the owner of pair id i is i % world in a sharded set, i // pairs otherwise)."""
-    owner = torch.remainder(all_ids, world) if lomatch else torch.div(all_ids, per_fwd, rounding_mode='floor')
+def count_ranks(all_ids, lomatch, per_rank, world):
+    """Ranks whose poses arrived through the gather (the owner of pair id i is i % world in a sharded set, i // (pairs per rank) otherwise)."""
+    owner = torch.remainder(all_ids, world) if lomatch else torch.div(all_ids, per_rank, rounding_mode='floor')
     return int(torch.unique(owner).numel())
 
 
@@ -610,13 +619,14 @@ def run_stub(args, rank, world, dist):
     """tests/test_bench_entry.py: the launch / sharding / gather / reporting logic of this script on CPU (gloo) with a
     stand-in for the forward -- no kernels, no claims; prints the same JSON shape with metric 'stub'."""
     cpu = torch.device('cpu')
+    args.replicas = 1
     lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, cpu)
     eye = torch.eye(3, 4).reshape(1, 3, 4)
 
     def step():
         return torch.cat([eye + pair_ids[lo:hi, None, None].float() for lo, hi in chunks]), None
     elapsed, all_poses, all_ids, _, per_rank = timed_passes(args, dist, lomatch, pair_ids, step, lambda: None, cpu)
-    ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)
+    ranks_seen = count_ranks(all_ids, lomatch, int(pair_ids.numel()), world)
     assert all_poses.shape[0] == pairs_per_step and ranks_seen == world
     assert torch.equal(all_poses[:, 0], 1 + all_ids.float())
     assert torch.equal(all_ids, torch.sort(all_ids)[0]) and (not lomatch or torch.equal(all_ids.long(), torch.arange(args.total_pairs)))
@@ -646,12 +656,17 @@ def main():
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
     ap.add_argument('--parity-pairs', type=int, default=8, help='pairs of the last timed step checked against the CPU oracle: first, last, largest, smallest slot of the batch + evenly spaced others (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
-    ap.add_argument('--pairs', type=int, default=0, help='pairs per step per GPU (one forward; default 192 for 3dmatch, 256 for modelnet, at most 192 per forward for lomatch -- a shard is cut into equal forwards; pairs are independent, 288 GB of HBM holds far more)')
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per FORWARD (default 64 for 3dmatch -- three forwards in flight, see --replicas: 192 pairs per step --, 256 for modelnet, at most 64 per forward for lomatch: a shard is cut into equal forwards; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--real', action='store_true', help='3dmatch: the three REAL pairs the reference ships (demo.py:26-49; tests/golden fixtures) replicated to --pairs under random rigid motions, instead of synthetic rooms')
     ap.add_argument('--head-init', choices=['uniform', 'probe'], default=None, help="output layer of the correspondence head: U(-0.5, 0.5) (3dmatch default) or a linear probe for the tokens' coordinates (modelnet default): bench.probe_head")
     ap.add_argument('--settle-s', type=float, default=5.0, help='set-up: seconds of untimed passes before the warm-up steps (the first seconds of sustained GPU work are slow on some boxes; 0 = off)')
+    ap.add_argument('--replicas', type=int, default=0,
+                    help='concurrent forwards per GPU: R model replicas on R host threads / HIP streams, each running its own --pairs-pair forwards (a step = R '
+                         'forwards = R x --pairs pairs).  Default 3 for the 3dmatch / lomatch configurations (3 x 64 pairs: +6 % over one 192-pair forward at a time -- '
+                         'forwards in flight fill each other\'s host waits and 5-6 ms heads; workload.ReplicaRunner), 1 for modelnet, parity mode and --pairs < 32; '
+                         '`--pairs 192 --replicas 1` = the round-5 line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-real', action='store_true', help='skip the side measurement of the same configuration on the shipped real fragments (real_fragments_pairs_per_s)')
     ap.add_argument('--no-roofline', action='store_true')
@@ -717,6 +732,8 @@ def main():
     torch.cuda.set_device(dev)
 
     dtype = args.dtype or ('bf16' if args.config == 'modelnet' else 'fp32')
+    if args.replicas < 1:
+        args.replicas = 1 if (args.parity_mode or (args.pairs and args.pairs < 32)) else DEFAULT_REPLICAS[args.config]
     lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, dev)
     n_local = int(pair_ids.numel())
     if args.real and args.config != '3dmatch':
@@ -726,17 +743,23 @@ def main():
     if args.no_range_check:
         model._range_check = False
 
+    n_rep = min(args.replicas, len(chunks))
+    runner = ReplicaRunner(replicate(model, cfg, n_rep, dev), batch, chunks, dev)
+
     def step():
-        poses, out = [], None
-        for lo, hi in chunks:
-            out = model({'src_xyz': batch['src_xyz'][lo:hi], 'tgt_xyz': batch['tgt_xyz'][lo:hi]})
-            poses.append(out['pose'][-1])
-        return (poses[0] if len(poses) == 1 else torch.cat(poses)), out
+        outs = runner.run(1)
+        return runner.poses(outs), outs[-1]
+
+    def many(n):
+        outs = runner.run(n)
+        return runner.poses(outs), outs[-1]
+    if n_rep > 1:
+        step.many = many
     settle = settle_device(step, args.settle_s)
     elapsed, all_poses, all_ids, last_out, per_rank = timed_passes(args, dist, lomatch, pair_ids, step, torch.cuda.synchronize, dev)
     peak_gb = torch.cuda.max_memory_allocated(dev) / 2**30       # inputs, weights and every buffer of the forwards so far
     assert all_poses.shape[0] == pairs_per_step and torch.isfinite(all_poses).all()
-    ranks_seen = count_ranks(all_ids, lomatch, per_fwd, world)                                      # who entered the all_gather
+    ranks_seen = count_ranks(all_ids, lomatch, n_local, world)                                      # who entered the all_gather
     assert ranks_seen == world, (ranks_seen, world)
 
     if rank == 0:
@@ -769,7 +792,9 @@ def main():
             'higher_is_better': True, 'scaling': 'strong' if lomatch else 'weak', 'vs_baseline': None,
             'dtype': {'fp32': 'f32 (f16-pair split, 22-bit operands)', 'fp32x3': 'f32 (bf16x3 split, 24-bit operands)'}.get(dtype, dtype),
             'data': 'real 3DMatch fragments (3 shipped pairs, replicated under random rigid motions)' if args.real else 'synthetic',
-            'config': {'workload': workload, 'pairs_per_step_per_gpu': args.pairs, 'points_per_cloud': mean_pts,
+            'config': {'workload': workload, 'pairs_per_step_per_gpu': n_local, 'pairs_per_forward': [hi - lo for lo, hi in chunks], 'concurrent_forwards': n_rep,
+                       'concurrency': (f'{n_rep} model replicas on {n_rep} host threads / HIP streams, each running its own forwards (workload.ReplicaRunner); timed steps free-running' if n_rep > 1 else 'one forward at a time'),
+                       'points_per_cloud': mean_pts,
                        'arch': f'conf/{"3dmatch" if lomatch else args.config}.yaml, random-init weights; head output layer: ' + ('U(-0.5, 0.5) (predictions spread over metres: a well-conditioned Procrustes problem)' if model.head_init == 'uniform' else f"linear probe for the tokens' own coordinates fitted on 4 calibration pairs (r^2 {model.head_probe_r2:.2f}; bench.probe_head: correspondences correlated with the key points, as a trained head's are -- a well-conditioned Procrustes problem)"), 'compute_dtype': dtype, 'shuffle': bool(args.shuffle),
                        'parallelism': f'pair-sharded x{world}, ONE RCCL all_gather_into_tensor of the (pose | id) rows', 'peak_hbm_allocated_GiB': round(peak_gb, 2),
                        'settle': dict(settle, what='untimed set-up passes before the warm-up steps (bench.settle_device)'),

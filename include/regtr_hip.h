@@ -222,7 +222,7 @@ int regtr_gemm_x3_tile_rows(int M, int N, int K);
 /* n_planes: 3 = the float32-grade six-term product (default everywhere); 2 = three leading terms (a0 w0 + a0 w1 + a1 w0,
  * ~2^-16 relative per product); 1 = plain bf16 operands with float32 accumulation (cfg.compute_dtype 'bf16').  1 and 2 do not
  * combine with a_stats / stat_partial (the KPConv encoder always runs float32-grade). */
-/* One-shot strip variant for the shallow encoder levels (K in {32, 64, 128}, N <= 256, millions of rows; csrc/gemm_stream.hip):
+/* One-shot strip variant for the shallow encoder levels (K in {32, 64, 128}, N <= 512, millions of rows; csrc/gemm_stream.hip):
  * every wave takes 32 rows from global memory straight into MFMA fragments, the weight planes sit in LDS per 256-row workgroup,
  * nothing is loaded after a store.  Same float32-grade product as regtr_gemm_x3:  C = A' W.
  *   a_stats [n_seg,K,2] (K <= 64): A' = LeakyReLU_a_slope(InstanceNorm(A)); seg_off [n_seg+1]: cloud offsets of the rows;

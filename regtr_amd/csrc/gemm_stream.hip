@@ -1,5 +1,5 @@
 // One-shot strip GEMM for the SHALLOW encoder levels: C[M, N] = epilogue(A'[M, K] W[K, N]) with K in {32, 64, 128} input
-// columns, N <= 256 outputs and millions of rows -- the UnaryBlock / shortcut Linears of the first two KPConv levels
+// columns, N <= 512 outputs and millions of rows -- the UnaryBlock / shortcut Linears of the KPConv levels with >= 131072 rows
 // (/root/reference/src/models/backbone_kpconv/kpconv_blocks.py:556-561, 722-741).  Float32-grade on the bf16 matrix cores by the
 // same exact three-way split as gemm_x3.hip (six v_mfma_f32_32x32x16_bf16 per product block, smallest terms first).
 //

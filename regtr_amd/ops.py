@@ -315,7 +315,7 @@ def stream_ok(M, N, K, a, a_stats=None):
 
 
 def gemm_stream(a, sw, seg_off, a_stats=None, a_slope=0.1, want_stats=False, eps=1e-5):
-    """regtr_gemm_stream: a' @ W for K in {32, 64, 128}, N <= 256 on millions of rows (see csrc/gemm_stream.hip).
+    """regtr_gemm_stream: a' @ W for K in {32, 64, 128}, N <= 512 on millions of rows (see csrc/gemm_stream.hip).
     want_stats: also return the per-cloud InstanceNorm (mean, rstd) table of the result.  -> out | (out, stats)"""
     L = _lib.lib()
     M, K = a.shape

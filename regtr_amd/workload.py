@@ -21,11 +21,15 @@ def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
     return nq * H * (4 + 12 + 4 * cin) + nq * (12 + 4 * cout) + kp * cin * cout * 4
 
 
-# pairs per forward when --pairs is not given.  3dmatch: 192 since round 5 -- the same kernels, 2.8-3.8 % more pairs/s than 64 per forward on one
-# box (64 / 96 / 128 / 192: 2366 / 2433 / 2410-2423 / 2455 pairs/s, profiles/r05_z_batch_sweep.txt; 20.8 GiB of the 288 GB): a forward's fixed costs
-# -- host set-up, the two host reads, the last partial round of every launch's workgroups -- are spread over three times the pairs.  lomatch: at most 192
-# per forward, a shard cut into EQUAL forwards (bench.plan_pairs: a 223-pair shard is 112 + 111), modelnet 256.
-DEFAULT_PAIRS = {'3dmatch': 192, 'modelnet': 256, 'lomatch': 192}
+# pairs per forward and concurrent forwards per GPU when --pairs / --replicas are not given.
+# 3dmatch: THREE concurrent 64-pair forwards = 192 pairs per step (round 6).  Rounds 1-4 ran one 64-pair forward at a time, round 5 one 192-pair
+# forward (+3 %: fixed costs spread over three times the pairs).  A forward has two host waits and a 5-6 ms head during which nothing else of it
+# can run, so a second and third forward in flight (ReplicaRunner below) fill the chip: same box, pairs/s, one forward at a time -> R threads:
+# 3 x 64: 2009 -> 2257 / 2223 / 2219;  2 x 64: 2037 -> 2187;  4 x 64: 2062 -> 2193 / 2128 / 2166;  2 x 96: 2062 -> 2182;  4 x 96: 2058 -> 2213 / 2197;
+# 3 x 128: 2056 -> 2171;  2 x 192: 2085 -> 2158;  3 x 192: 2105 -> 2203;  one 192-pair forward: 2085-2117  (profiles/r06_m_concurrency_sweep.txt).
+# lomatch: at most 64 per forward, a shard cut into EQUAL forwards (bench.plan_pairs), three in flight; modelnet: one 256-pair forward.
+DEFAULT_PAIRS = {'3dmatch': 64, 'modelnet': 256, 'lomatch': 64}
+DEFAULT_REPLICAS = {'3dmatch': 3, 'modelnet': 1, 'lomatch': 3}
 REDUCED_TOL = {'correspondence': 2e-2, 'pose': 1e-1}      # gate of the bf16 / bf16x2 lines against the float32-grade run (see main)
 
 REAL_PAIRS = ('3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at')     # tests/golden/*.npz: the clouds of /root/reference/src/demo.py:26-49 examples 0-2
@@ -188,3 +192,85 @@ def forward_matrix_seconds(gemm_records, gemm_reps, gather_records, gather_reps,
     f_gather = sum(r[3] * r[4] * (150.0 + 30.0 * r[5]) for r in gather_records) / gather_reps
     return {'dense_s': dense, 'gather_s': f_gather / (MFMA_F32_PEAK_TFS * 1e12), 'attention_s': attention_flops * attention_terms / (MFMA_BF16_PEAK_TFS * 1e12),
             'algorithmic_flops': f_dense + f_gather + attention_flops, 'issued_flops': f_dense_issued + f_gather + attention_flops * attention_terms}
+
+
+class ReplicaRunner:
+    """Concurrent forwards of one GPU (round 6): R model replicas (same weights) driven by R host threads on R HIP streams, replica r taking the
+    chunks r, r + R, ... of the batch.  Why: a forward has two host waits (the pyramid's level sizes, the status word) and a 5-6 ms head (cell grid +
+    level-0 conv table) during which nothing else of it can run, so ONE thread cannot keep the chip busy across forwards; a second forward in flight
+    fills both.  Measured on one box (tools/concurrency_probe.py, profiles/r06_k_concurrency.txt): 2 x 192 pairs +4.1 %, 3 x 192 +4.7 %, 4 x 192 +3.1 %,
+    3 x 128 +6.1 % over the same forwards one after the other -- poses bit-identical.  Replicas, not one shared module: a model owns its
+    preprocessing workspaces.  `run(n)` lets every thread run its chunks n times WITHOUT meeting the others in between (free-running threads settle
+    into a stagger; a join per step would start every forward's head at the same moment) and returns the outputs of the last pass per chunk."""
+
+    def __init__(self, models, batch, chunks, device):
+        import threading
+        self._threading = threading
+        self.models, self.batch, self.chunks, self.device = list(models), batch, list(chunks), torch.device(device)
+        self.R = len(self.models)
+        self.cuda = self.device.type == 'cuda'
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.R)] if (self.cuda and self.R > 1) else [None] * self.R
+
+    def _chunk(self, lo, hi):
+        return {'src_xyz': self.batch['src_xyz'][lo:hi], 'tgt_xyz': self.batch['tgt_xyz'][lo:hi]}
+
+    def _work(self, r, n, outs, errs):
+        try:
+            mine = list(range(r, len(self.chunks), self.R))
+
+            def loop():
+                for _ in range(n):
+                    for c in mine:
+                        outs[c] = self.models[r](self._chunk(*self.chunks[c]))
+            if self.streams[r] is not None:
+                with torch.cuda.device(self.device), torch.cuda.stream(self.streams[r]):
+                    loop()
+            else:
+                loop()
+        except BaseException as e:          # re-raised on the calling thread
+            errs.append(e)
+
+    def run(self, n=1):
+        """n passes over the batch -> [output dict of the last pass for chunk 0, 1, ...] (enqueued; the caller synchronises)."""
+        outs, errs = [None] * len(self.chunks), []
+        if self.R == 1:
+            self._work(0, n, outs, errs)
+        else:
+            cur = torch.cuda.current_stream(self.device) if self.cuda else None
+            for s in self.streams:
+                if s is not None:
+                    s.wait_stream(cur)                    # the inputs (and whatever the caller enqueued before)
+            th = [self._threading.Thread(target=self._work, args=(r, n, outs, errs)) for r in range(self.R)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            for s in self.streams:
+                if s is not None:
+                    cur.wait_stream(s)                    # the caller's stream sees every replica's results
+        if errs:
+            raise errs[0]
+        return outs
+
+    def poses(self, outs):
+        """(n_pairs, 3, 4) final-layer poses in batch order, safe to use on the current stream."""
+        ps = [o['pose'][-1] for o in outs]
+        p = ps[0] if len(ps) == 1 else torch.cat(ps)
+        if self.cuda and self.R > 1:
+            for x in ps:
+                x.record_stream(torch.cuda.current_stream(self.device))
+        return p
+
+
+def replicate(model, cfg, n, device):
+    """[model, n - 1 replicas with the same weights] (RegTR modules own their preprocessing workspaces: concurrent forwards need one module each)."""
+    from regtr_amd import RegTR
+    out = [model]
+    for _ in range(n - 1):
+        m = RegTR(cfg).to(device).eval()
+        m.load_state_dict(model.state_dict())
+        for attr in ('head_init', 'head_probe_r2', '_range_check'):
+            if hasattr(model, attr):
+                setattr(m, attr, getattr(model, attr))
+        out.append(m)
+    return out

@@ -40,8 +40,8 @@ parser.add_argument('--num_workers', type=int, default=-1,
                          'thread for a 16-core quota and slow the set down)')
 parser.add_argument('--resume', type=str, help='Checkpoint to resume from')
 # harness options (not in the reference)
-parser.add_argument('--batch', type=int, default=192,
-                    help='pairs per forward (192 = the measured throughput configuration of bench.py, whose line reports the HBM it allocates: ~21 GiB; 1 = the reference loop)')
+parser.add_argument('--batch', type=int, default=64,
+                    help='pairs per forward (64: end to end over the 1781-pair set 1762 pairs/s against 1668 at 192 -- ten forwards do not amortise the pipeline fill; bench.py measures 192 on resident inputs; 1 = the reference loop)')
 parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.root (folder holding test/<scene>/cloud_bin_*.pth)')
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')

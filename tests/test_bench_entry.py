@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -42,12 +44,12 @@ def test_lomatch_set_is_sharded_and_gathered_every_pass():
 
 def test_lomatch_1781_pairs_on_eight_ranks():
     """The world-8 rehearsal of configs[3] that needs no 8-GPU node: `bench.py --gpus 8 --config lomatch --total-pairs 1781` on gloo with the
-    stand-in forward -- 223 / 222-row shards (ragged), at most 192 per forward cut into EQUAL forwards (112 + 111 on rank 0), every pose
+    stand-in forward -- 223 / 222-row shards (ragged), at most 64 per forward cut into EQUAL forwards (56 + 56 + 56 + 55 on rank 0), every pose
     on every rank in pair order after each pass (asserted inside run_stub), eight ranks seen through the gather."""
     r = _run(['--gpus', '8', '--config', 'lomatch', '--total-pairs', '1781', '--steps', '2', '--warmup', '1', '--stub-backend', 'gloo'])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
-    assert d['n_gpus'] == 8 and d['pairs_per_step'] == 1781 and d['forwards_per_step_rank0'] == 2 and d['scaling'] == 'strong'
+    assert d['n_gpus'] == 8 and d['pairs_per_step'] == 1781 and d['forwards_per_step_rank0'] == 4 and d['scaling'] == 'strong'
     assert len(d['per_rank_ms_per_step']) == 8
 
 
@@ -129,12 +131,12 @@ def test_settle_phase_has_a_fixed_length_and_reports_its_passes():
     r = bench.settle_device(lambda: (calls.append(1), time.sleep(0.01)), 0.15, sync=lambda: None)
     assert r['passes'] == len(calls) >= 5 and 0.15 <= r['seconds'] < 1.0 and len(r['first_ms']) == 3 and all(t >= 9.0 for t in r['last_ms'])
     assert bench.settle_device(lambda: calls.append(1), 0.0, sync=lambda: None)['passes'] == 0
-    assert bench.DEFAULT_PAIRS == {'3dmatch': 192, 'modelnet': 256, 'lomatch': 192} and bench.REDUCED_TOL['pose'] <= 0.1
+    assert bench.DEFAULT_PAIRS == {'3dmatch': 64, 'modelnet': 256, 'lomatch': 64} and bench.DEFAULT_REPLICAS == {'3dmatch': 3, 'modelnet': 1, 'lomatch': 3} and bench.REDUCED_TOL['pose'] <= 0.1
 
 
 def test_plan_pairs_equal_forwards_and_rank_emulation():
-    """bench.plan_pairs: a lomatch shard is cut into the fewest forwards of at most --pairs pairs, then into EQUAL ones (223 -> 112 + 111, not
-    192 + 31); --emulate-rank-of 8 gives one GPU rank 0's shard of an 8-rank job (the strong-scaling prediction of DESIGN section 7)."""
+    """bench.plan_pairs: a lomatch shard is cut into the fewest forwards of at most --pairs pairs, then into EQUAL ones (223 -> 56 + 56 + 56 + 55, not
+    64 x 3 + 31); the default configuration is three concurrent 64-pair forwards per rank and step; --emulate-rank-of 8 gives one GPU rank 0's shard of an 8-rank job (the strong-scaling prediction of DESIGN section 7)."""
     import argparse
     import sys
     import torch
@@ -142,10 +144,45 @@ def test_plan_pairs_equal_forwards_and_rank_emulation():
     import bench
     a = argparse.Namespace(config='lomatch', pairs=0, total_pairs=1781, emulate_rank_of=8)
     lomatch, per_fwd, ids, chunks, per_step = bench.plan_pairs(a, 0, 1, torch.device('cpu'))
-    assert lomatch and per_fwd == 192 and ids.tolist() == list(range(0, 1781, 8)) and chunks == [(0, 112), (112, 223)] and per_step == 223
+    assert lomatch and per_fwd == 64 and ids.tolist() == list(range(0, 1781, 8)) and [hi - lo for lo, hi in chunks] == [56, 56, 56, 55] and per_step == 223
+    a = argparse.Namespace(config='lomatch', pairs=192, total_pairs=1781, emulate_rank_of=8)
+    assert bench.plan_pairs(a, 0, 1, torch.device('cpu'))[3] == [(0, 112), (112, 223)]
     a = argparse.Namespace(config='lomatch', pairs=64, total_pairs=1781, emulate_rank_of=0)
     _, _, ids, chunks, per_step = bench.plan_pairs(a, 3, 8, torch.device('cpu'))
     assert ids.tolist() == list(range(3, 1781, 8)) and [hi - lo for lo, hi in chunks] == [56, 56, 56, 55] and per_step == 1781
-    a = argparse.Namespace(config='3dmatch', pairs=0, total_pairs=1781, emulate_rank_of=0)
+    a = argparse.Namespace(config='3dmatch', pairs=0, total_pairs=1781, emulate_rank_of=0, replicas=3)
     _, per_fwd, ids, chunks, per_step = bench.plan_pairs(a, 1, 2, torch.device('cpu'))
-    assert per_fwd == 192 and ids[0] == 192 and chunks == [(0, 192)] and per_step == 384
+    assert per_fwd == 64 and ids[0] == 192 and chunks == [(0, 64), (64, 128), (128, 192)] and per_step == 384
+
+
+def test_replica_runner_orders_chunks_and_propagates_errors():
+    """workload.ReplicaRunner on CPU with stand-in models: replica r runs chunks r, r + R, ...; run(n) returns the last pass's outputs in CHUNK
+    order; poses() concatenates them in batch order; an exception on a worker thread surfaces on the caller."""
+    import sys
+    import threading
+    import torch
+    sys.path.insert(0, ROOT)
+    from regtr_amd.workload import ReplicaRunner
+    batch = {'src_xyz': [torch.full((2, 3), float(i)) for i in range(7)], 'tgt_xyz': [torch.zeros(2, 3) for _ in range(7)]}
+    chunks = [(0, 3), (3, 5), (5, 7)]
+    calls = []
+
+    def make(tag):
+        def model(b):
+            calls.append((tag, threading.get_ident(), len(b['src_xyz'])))
+            ids = torch.stack([x[0, 0] for x in b['src_xyz']])
+            return {'pose': (torch.eye(3, 4)[None, None] + ids[None, :, None, None]).repeat(6, 1, 1, 1)}
+        return model
+    r = ReplicaRunner([make('a'), make('b')], batch, chunks, torch.device('cpu'))
+    outs = r.run(2)
+    assert len(outs) == 3 and [o['pose'].shape[1] for o in outs] == [3, 2, 2]
+    assert torch.equal(r.poses(outs)[:, 0, 0], 1 + torch.arange(7.0))
+    assert sorted(c[0] + str(c[2]) for c in calls) == ['a2', 'a2', 'a3', 'a3', 'b2', 'b2']       # replica a: chunks 0 and 2, replica b: chunk 1, two passes
+    assert len({c[1] for c in calls}) == 2
+    one = ReplicaRunner([make('c')], batch, chunks, torch.device('cpu'))
+    assert torch.equal(one.poses(one.run(1)), r.poses(outs))
+
+    def broken(b):
+        raise ValueError('boom')
+    with pytest.raises(ValueError, match='boom'):
+        ReplicaRunner([make('a'), broken], batch, chunks, torch.device('cpu')).run(1)

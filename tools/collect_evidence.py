@@ -25,6 +25,7 @@ def main():
     for name, out in (('forward_trace.md', 'forward_trace.md'), ('kernel_stats.md', 'kernel_stats.md'), ('pmc_mfma.md', 'pmc_mfma.md'),
                       ('forward_trace_pairs1.md', 'forward_trace_pairs1.md'), ('kernel_stats_pairs1.md', 'kernel_stats_pairs1.md'),
                       ('forward_trace_real.md', 'forward_trace_real.md'), ('kernel_stats_real.md', 'kernel_stats_real.md'),
+                      ('kernel_stats_concurrent.md', 'kernel_stats_concurrent.md'), ('kernel_stats_pairs192.md', 'kernel_stats_pairs192.md'), ('forward_trace_pairs192.md', 'forward_trace_pairs192.md'),
                       ('host_profile_p1.txt', 'host_profile_pairs1.txt'), (f'{a.tag}_pmc_traffic_kernels.md', 'pmc_traffic_kernels.md')):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f'{a.tag}_{out}'))

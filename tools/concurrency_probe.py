@@ -1,7 +1,10 @@
-"""GPU: two half-size forwards on two host threads / two HIP streams against one full-size forward.
-    python tools/concurrency_probe.py [pairs=192] [steps=12]
-Round 2's micro-batch loss was measured at 16-32 pairs per forward, where launches shrink below the chip; at 96 pairs the per-launch rates are on the
-plateau (profiles/r05_z_batch_sweep.txt), so the question is only whether issue-bound gathers co-issue with waitcnt-bound GEMMs of the OTHER forward."""
+"""GPU: forwards on two host threads / two HIP streams against the same forwards one after the other.
+    python tools/concurrency_probe.py [pairs per forward=96] [steps=12] [replicas=2]
+Two MODEL REPLICAS (same weights), one per thread, each with its own batch of `pairs` pairs: a forward has two host waits (the pyramid's level sizes,
+the status word), so one thread cannot keep the chip busy across forwards; a second thread's forward fills the 5-6 ms head of the first (cell grid
++ level-0 conv table, during which nothing else of that forward can run) and its host gaps.
+Round 6: 2 x 96 pairs against one 192-pair forward: +1.9 % (below the bar: halving the batch costs ~6 % by itself).
+This form answers the follow-up: 2 x 192 pairs concurrently against 2 x 192 one after the other."""
 import os
 import sys
 import threading
@@ -11,18 +14,19 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
+from regtr_amd import RegTR  # noqa: E402
 
-pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dev = torch.device('cuda:0')
-cfg, model, prs, batch = bench.build_workload('3dmatch', pairs, 20000, False, 0, dev, 'fp32')
-half = pairs // 2
-halves = [{k: v[:half] for k, v in batch.items()}, {k: v[half:] for k, v in batch.items()}]
-
-
-def run_full(n):
-    for _ in range(n):
-        model(dict(batch))
+cfg, model, prs, batch = bench.build_workload('3dmatch', R * pairs, 20000, False, 0, dev, 'fp32')
+halves = [{k: v[i * pairs:(i + 1) * pairs] for k, v in batch.items()} for i in range(R)]
+models = [model]
+for _ in range(R - 1):
+    twin = RegTR(cfg).to(dev).eval()
+    twin.load_state_dict(model.state_dict())
+    models.append(twin)
 
 
 def timed(fn):
@@ -33,28 +37,33 @@ def timed(fn):
     return (time.perf_counter() - t0) / steps
 
 
-def run_seq_halves(n):
+def run_seq(n):
     for _ in range(n):
-        model(dict(halves[0])); model(dict(halves[1]))
+        for h in halves:
+            models[0](dict(h))
+
+
+outs = [None] * R
 
 
 def run_threads(n):
     def worker(i):
-        st = streams[i]
-        with torch.cuda.stream(st), torch.no_grad():
+        with torch.cuda.stream(streams[i]), torch.no_grad():
             for _ in range(n):
-                model(dict(halves[i]))
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+                outs[i] = models[i](dict(halves[i]))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(R)]
     for t in th: t.start()
     for t in th: t.join()
 
 
 with torch.no_grad():
-    t_full = timed(run_full)
-    t_seq = timed(run_seq_halves)
-    for prio in (None, (0, 0), (-1, 0)):
-        streams = [torch.cuda.Stream(dev) if prio is None else torch.cuda.Stream(dev, priority=prio[i]) for i in range(2)]
+    ref = [models[0](dict(h))['pose'].clone() for h in halves]
+    t_seq = timed(run_seq)
+    print(f'{R} forwards of {pairs} pairs, one after the other, one thread:            {t_seq * 1e3:7.2f} ms per {R * pairs} pairs = {R * pairs / t_seq:7.1f} pairs/s')
+    for prio in (None,):
+        streams = [torch.cuda.Stream(dev) for i in range(R)]
         t_thr = timed(run_threads)
-        print(f'two threads x {half} pairs on two streams (priorities {prio}): {t_thr * 1e3:7.2f} ms per {pairs} pairs = {pairs / t_thr:7.1f} pairs/s')
-    print(f'one forward of {pairs} pairs:                                   {t_full * 1e3:7.2f} ms = {pairs / t_full:7.1f} pairs/s')
-    print(f'two forwards of {half} pairs, one after the other, one thread:    {t_seq * 1e3:7.2f} ms = {pairs / t_seq:7.1f} pairs/s')
+        same = all(torch.equal(outs[i]['pose'], ref[i]) for i in range(R))
+        print(f'{R} threads x {pairs} pairs, {R} model replicas, {R} streams: {t_thr * 1e3:7.2f} ms per {R * pairs} pairs = {R * pairs / t_thr:7.1f} pairs/s'
+              f'  ({(t_seq / t_thr - 1) * 100:+.1f} %; poses bit-identical to the sequential run: {same})')
+    print('peak GiB', round(torch.cuda.max_memory_allocated() / 2**30, 2))
