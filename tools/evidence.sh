@@ -24,11 +24,11 @@ prof "" --replicas 1 --steps 8 --warmup 2
 prof _concurrent --steps 5 --warmup 2
 prof _pairs192 --replicas 1 --pairs 192 --steps 4 --warmup 2
 prof _pairs1 --pairs 1 --steps 50 --warmup 10
-prof _real --real --steps 4 --warmup 2
+prof _real --real --replicas 1 --pairs 192 --steps 4 --warmup 2
 pmc() { n=$1; shift; timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/pmc_$n -o p -- python bench.py --replicas 1 --pairs 192 --steps 2 --warmup 1 --settle-s 0 --no-cpu-baseline --no-roofline --parity-pairs 0 --no-strict-f32 --no-real > $out/pmc_$n.log 2>&1 || tail -3 $out/pmc_$n.log; }
 pmc 3 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE
 python tools/pmc_summary.py --mfma $out > $out/pmc_mfma.md 2>&1; head -14 $out/pmc_mfma.md; find $out -name "*.csv" -size +4M -delete
-for cfg in "--replicas 1 --steps 40 --warmup 5" "--pairs 192 --replicas 1 --steps 20 --warmup 3" "--pairs 192 --replicas 2 --steps 10 --warmup 3" "--real --steps 10 --warmup 3" "--real --replicas 1 --pairs 192 --steps 10 --warmup 3" "--pairs 1 --steps 300 --warmup 30" "--pairs 3 --steps 100 --warmup 10" "--pairs 8 --steps 50 --warmup 5" "--shuffle --steps 10 --warmup 2" "--points 100000 --pairs 8 --steps 6 --warmup 2" "--config modelnet --steps 10 --warmup 2" "--config modelnet --pairs 128 --replicas 2 --steps 10 --warmup 2" "--config modelnet --dtype fp32 --steps 10 --warmup 2" "--parity-mode --pairs 64 --steps 5 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --steps 3 --warmup 1" "--config lomatch --total-pairs 1781 --emulate-rank-of 2 --steps 5 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --emulate-rank-of 4 --steps 8 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --emulate-rank-of 8 --steps 12 --warmup 3 --no-roofline" "--dtype fp32x3 --steps 10 --warmup 2"; do
+for cfg in "--replicas 1 --steps 40 --warmup 5" "--pairs 192 --replicas 1 --steps 20 --warmup 3" "--pairs 192 --replicas 2 --steps 10 --warmup 3" "--real --steps 10 --warmup 3" "--real --replicas 1 --pairs 192 --steps 10 --warmup 3" "--pairs 1 --steps 300 --warmup 30" "--pairs 3 --steps 100 --warmup 10" "--pairs 8 --steps 50 --warmup 5" "--shuffle --steps 10 --warmup 2" "--points 100000 --pairs 8 --steps 6 --warmup 2" "--config modelnet --steps 10 --warmup 2" "--config modelnet --pairs 256 --replicas 1 --steps 10 --warmup 2" "--config modelnet --dtype fp32 --steps 10 --warmup 2" "--parity-mode --pairs 64 --steps 5 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --steps 3 --warmup 1" "--config lomatch --total-pairs 1781 --emulate-rank-of 2 --steps 5 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --emulate-rank-of 4 --steps 8 --warmup 2 --no-roofline" "--config lomatch --total-pairs 1781 --emulate-rank-of 8 --steps 12 --warmup 3 --no-roofline" "--dtype fp32x3 --steps 10 --warmup 2"; do
   t=$(echo $cfg | tr -d ' -' | cut -c1-44)
   timeout 600 python bench.py $cfg --no-cpu-baseline --no-strict-f32 --no-real > $out/bench_$t.json 2> $out/bench_$t.err; echo "exit $?" >> $out/bench_$t.err
   python - <<PY
