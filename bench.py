@@ -895,17 +895,17 @@ def main():
             cfg3.update({'compute_dtype': 'fp32x3'})
             m3 = RegTR(cfg3).to(dev).eval()
             m3.load_state_dict(model.state_dict())
-            cfg.update({'compute_dtype': dtype})
+            run3 = ReplicaRunner(replicate(m3, cfg3, n_rep, dev), batch, chunks, dev)       # the same forwards in flight as the timed line
+            cfg.update({'compute_dtype': dtype})                                            # (cfg3 may alias cfg)
             k3 = max(2, min(args.steps, 8))
-            for _ in range(2):
-                m3(dict(fwd_batch))
+            run3.run(2)
             torch.cuda.synchronize(); t3 = time.perf_counter()
-            for _ in range(k3):
-                o3 = m3(dict(fwd_batch))
+            o3 = run3.run(k3)
             torch.cuda.synchronize(); t3 = (time.perf_counter() - t3) / k3
-            res['fp32x3_pairs_per_s'] = len(fwd_batch['src_xyz']) / t3      # strictly 24-bit operands, same weights and batch, this run
-            res['config']['fp32x3_same_workload'] = {'value': len(fwd_batch['src_xyz']) / t3, 'unit': 'pairs/s', 'ms_per_step': t3 * 1e3, 'steps': k3,
-                                                     'max_abs_pose_vs_default': float((o3['pose'] - model(dict(fwd_batch))['pose']).abs().max())}
+            res['fp32x3_pairs_per_s'] = n_local / t3      # strictly 24-bit operands, same weights, batch and concurrency, this run
+            res['config']['fp32x3_same_workload'] = {'value': n_local / t3, 'unit': 'pairs/s', 'ms_per_step': t3 * 1e3, 'steps': k3,
+                                                     'max_abs_pose_vs_default': float((o3[0]['pose'] - model(dict(fwd_batch))['pose']).abs().max())}
+            del run3, o3
             del m3
         if args.config == '3dmatch' and world == 1 and not args.real and not args.no_real and not args.parity_mode and args.points == 20000 and not args.shuffle:
             # the same configuration on the REAL fragments the reference ships (demo.py:26-49), same pairs per forward, measured in this run outside

@@ -579,28 +579,71 @@ def pose_errors(pred, gt):
 def run_test(model, pairs, batch, device, logger=None, max_pairs=None, num_workers=0, loader_pool=None):
     """Runs every pair of `pairs` (this rank's shard) through the model, B at a time.  loader_pool: a LoaderPool over `pairs` (loader
     processes forked by the caller, e.g. before the GPU was initialised); else num_workers > 0: a pool forked here for this pass;
-    0: one loader thread (Prefetcher).  Returns, on every rank, (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids,
-    timing dict)."""
+    0: one loader thread (Prefetcher).
+    model: one RegTR module, or a LIST of replicas with the same weights (regtr_amd.workload.replicate): R host threads then take batches off the
+    one loader in turn and run them on R HIP streams -- forwards in flight fill each other's host waits and heads (round 6; bench.py measures
+    +6 % for three 64-pair forwards in flight); the poses come back in pair-id order either way, bit-identical to the one-replica run.
+    Returns, on every rank, (poses (n_total, 3, 4) float32 numpy ordered by pair id, pair ids, timing dict)."""
+    import contextlib
+    import itertools
+    import threading
     import torch.distributed as dist
     rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     n = len(pairs) if max_pairs is None else min(len(pairs), max_pairs)
     mine = shard_pairs(n, rank, world)
-    model.eval()
-    poses, ids = [], []
+    models = list(model) if isinstance(model, (list, tuple)) else [model]
+    for m in models:
+        m.eval()
     t0 = time.perf_counter()
     if loader_pool is not None:
         loader = loader_pool.iterate(mine, batch)
     else:
         loader = BatchLoader(pairs, mine, batch, device, workers=num_workers) if num_workers > 0 else Prefetcher(pairs, mine, batch, device)
-    fwd_ms = []
-    with torch.no_grad():
-        for b in loader:
-            t_f = time.perf_counter()
-            out = model({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
-            fwd_ms.append(round((time.perf_counter() - t_f) * 1e3, 1))
-            poses.append(out['pose'][-1])                         # (B, 3, 4), stays on the device
-            ids.extend(b['ids'] if 'ids' in b else [it['idx'] for it in b['items']])
+    cuda = device.type == 'cuda'
+    R = len(models)
+    streams = [torch.cuda.Stream(device) for _ in range(R)] if (cuda and R > 1) else [None] * R
+    it, turn, counter = iter(loader), threading.Lock(), itertools.count()
+    done, errs, fwd_ms = [], [], []
+
+    def work(r):
+        try:
+            ctx = (torch.cuda.stream(streams[r]) if streams[r] is not None else contextlib.nullcontext())
+            dctx = torch.cuda.device(device) if cuda else contextlib.nullcontext()
+            with dctx, ctx, torch.no_grad():
+                while not errs:
+                    with turn:                                     # one loader, R consumers: batches are handed out in order
+                        try:
+                            b = next(it)
+                        except StopIteration:
+                            return
+                        k = next(counter)
+                    t_f = time.perf_counter()
+                    out = models[r]({'src_xyz': b['src_xyz'], 'tgt_xyz': b['tgt_xyz']})
+                    fwd_ms.append(round((time.perf_counter() - t_f) * 1e3, 1))
+                    done.append((k, out['pose'][-1], b['ids'] if 'ids' in b else [i_['idx'] for i_ in b['items']]))      # (B, 3, 4), stays on the device
+        except BaseException as e:      # noqa: BLE001  (re-raised on the caller)
+            errs.append(e)
+    if R == 1:
+        work(0)
+    else:
+        cur = torch.cuda.current_stream(device) if cuda else None
+        th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for s_ in streams:
+            if s_ is not None:
+                cur.wait_stream(s_)
+        for _, p_, _ in done:
+            if cuda:
+                p_.record_stream(cur)
+    if errs:
+        raise errs[0]
+    done.sort(key=lambda d: d[0])
+    poses = [d[1] for d in done]
+    ids = [i for d in done for i in d[2]]
     pose_t = torch.cat(poses).reshape(-1, 12) if poses else torch.zeros((0, 12), dtype=torch.float32, device=device)
     id_t = torch.tensor(ids, dtype=torch.int32, device=device)
     all_poses, all_ids = gather_poses(pose_t, id_t, n)

@@ -42,6 +42,9 @@ parser.add_argument('--resume', type=str, help='Checkpoint to resume from')
 # harness options (not in the reference)
 parser.add_argument('--batch', type=int, default=64,
                     help='pairs per forward (64: end to end over the 1781-pair set 1762 pairs/s against 1668 at 192 -- ten forwards do not amortise the pipeline fill; bench.py measures 192 on resident inputs; 1 = the reference loop)')
+parser.add_argument('--replicas', type=int, default=0,
+                    help='forwards in flight: R model replicas (same weights) on R host threads / HIP streams taking batches off the one loader in turn '
+                         '(regtr_amd/harness.py run_test; default 3 for --batch >= 32, else 1)')
 parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.root (folder holding test/<scene>/cloud_bin_*.pth)')
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
@@ -192,6 +195,10 @@ def main():
         logger.info(f'Loaded checkpoint {opt.resume} (step {state.get("step", "?")}); {missing}')
     else:
         logger.warning('No checkpoint given. Will perform inference using random weights')
+    # forwards in flight (round 6): replicas with the same weights, one per host thread / HIP stream (harness.run_test)
+    from regtr_amd.workload import replicate
+    n_rep = opt.replicas if opt.replicas > 0 else (3 if opt.batch >= 32 else 1)
+    models = replicate(model.eval(), cfg, n_rep, device)
 
     if not opt.no_warmup:
         # one untimed forward on a synthetic batch of the run's shape: the weights' one-time re-layout (split planes), the first growth
@@ -202,14 +209,15 @@ def main():
         gen = [(synth_pair(900001 + i, opt.warmup_points) if cfg.dataset == '3dmatch' else synth_modelnet_pair(900001 + i)) for i in range(2)]
         wb = {'src_xyz': [torch.from_numpy(gen[i % 2][0]).to(device) for i in range(opt.batch)],
               'tgt_xyz': [torch.from_numpy(gen[i % 2][1]).to(device) for i in range(opt.batch)]}
-        model.eval()
-        with torch.no_grad():
-            model(wb)
+        for m in models:             # every replica: its weights' re-layout, its workspaces
+            m.eval()
+            with torch.no_grad():
+                m(wb)
         torch.cuda.synchronize(device)
         del wb
         logger.info(f'warm-up forward ({opt.batch} synthetic pairs, untimed): {time.perf_counter() - t_w:.2f} s')
     t_run = time.perf_counter()
-    poses, ids, timing = harness.run_test(model, pairs, opt.batch, device, logger, opt.max_pairs, loader_pool=pool)
+    poses, ids, timing = harness.run_test(models if len(models) > 1 else model, pairs, opt.batch, device, logger, opt.max_pairs, loader_pool=pool)
     if pool is not None:
         logger.info(f'loader: {timing["loader"]}; forward ms (host clock, incl. the end-of-forward status wait): {timing["forward_ms"]}')
         pool.close()
@@ -226,7 +234,7 @@ def main():
             t_all = time.perf_counter() - t_run
             logger.info(f'est.log files written under {os.path.join(opt.log_path, opt.benchmark)}')
             logger.info(f'[End to end] {len(ids)} pairs, {"files -> " if from_files else "generator -> "}H2D -> forward -> pose gather -> est.log: '
-                        f'{t_all:.2f} s = {len(ids) / t_all:.1f} pairs/s on {timing["world"]} GPU(s), batch {opt.batch}, {workers} loader process(es)'
+                        f'{t_all:.2f} s = {len(ids) / t_all:.1f} pairs/s on {timing["world"]} GPU(s), batch {opt.batch}, {len(models)} forward(s) in flight, {workers} loader process(es)'
                         f'{", .npy cache" if opt.cache_dir else ""}')
             gt_folder = os.path.join(opt.benchmark_dir, opt.benchmark)
             complete = opt.max_pairs is None or opt.max_pairs <= 0 or opt.max_pairs >= len(pairs)

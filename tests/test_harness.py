@@ -231,3 +231,21 @@ def test_end_to_end_rate_vs_resident_inputs(tmp_path):
     assert np.allclose(poses[192:], out['pose'][-1].cpu().numpy(), atol=1e-5)
     print(f'256 pairs: resident inputs {256 / t_res:.0f} pairs/s, end to end (4 loader processes, .npy cache) {256 / best:.0f} pairs/s = {t_res / best:.2f} x; loader {tm["loader"]}')
     assert best <= t_res / 0.7, (best, t_res)
+
+
+@pytest.mark.gpu
+def test_run_test_with_three_replicas_equals_one(tmp_path):
+    """harness.run_test with three model replicas on three host threads / streams (round 6: forwards in flight) returns the poses of the
+    one-replica run bit for bit, in pair-id order -- ragged last batch, more batches than replicas."""
+    import torch
+    from regtr_amd import RegTR, harness, load_config
+    from regtr_amd.workload import replicate
+    dev = torch.device('cuda', 0)
+    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
+    torch.manual_seed(0)
+    model = RegTR(cfg).to(dev).eval()
+    pairs = harness.SyntheticPairs(23, points=3000)
+    p1, i1, _ = harness.run_test(model, pairs, 4, dev)
+    p3, i3, t3 = harness.run_test(replicate(model, cfg, 3, dev), pairs, 4, dev)
+    assert np.array_equal(i1, i3) and i1.tolist() == list(range(23)) and len(t3['forward_ms']) == 6
+    assert np.array_equal(p1, p3)
