@@ -217,6 +217,9 @@ constexpr float MHA_F16_SCALE = 2048.f;
 #ifndef MHA_PACKED
 #define MHA_PACKED 0                  // softmax / pair-split arithmetic on two-element vectors (v_pk_*_f32): measured SLOWER (below); A/B: -DMHA_PACKED=1
 #endif
+#ifndef MHA_WIDE_MIN_WG
+#define MHA_WIDE_MIN_WG 4096         // eight-wave workgroups only on launches with at least this many of them (A/B: -DMHA_WIDE_MIN_WG=..)
+#endif
 #ifndef MHA_WIDE
 #define MHA_WIDE 1                    // 8-wave workgroups for clouds of more than 128 tokens (A/B: -DMHA_WIDE=0)
 #endif
@@ -718,7 +721,7 @@ int regtr_mha_fwd(const float* q, int ldq, const float* k, int ldk, const float*
         // -- on launches of many rounds of workgroups only.  Measured (tools/mha_bench.py, profiles/r06_f_mha_wide.txt; us per launch, 4 -> 8 waves):
         // 384 clouds of 330-460 tokens, f16 pair 439.7 -> 419.5, bf16x3 553.7 -> 515.3; 512 clouds of 560-640, bf16 572.9 -> 554.9 (inside the
         // ModelNet forward 547 -> 464); but 128 clouds of 230-360 (2048 eight-wave workgroups, four rounds on 256 CUs x 2) 93.9 -> 110.8.
-        if (MHA_WIDE && max_len > BW * TQ && (long long)rg_cdiv(max_len, BW8 * TQ) * n_heads * n_clouds >= 4096) {
+        if (MHA_WIDE && max_len > BW * TQ && (long long)rg_cdiv(max_len, BW8 * TQ) * n_heads * n_clouds >= MHA_WIDE_MIN_WG) {
             const dim3 grid(rg_cdiv(max_len, BW8 * TQ), n_heads, n_clouds);
             if (precision == 0) k_mha_fwd_bf16<3, false, BW8><<<grid, BW8 * RG_WAVE, 0, st>>>(g);
             else if (precision == 3) k_mha_fwd_bf16<2, true, BW8><<<grid, BW8 * RG_WAVE, 0, st>>>(g);
