@@ -44,7 +44,7 @@ parser.add_argument('--batch', type=int, default=64,
                     help='pairs per forward (64: end to end over the 1781-pair set 1762 pairs/s against 1668 at 192 -- ten forwards do not amortise the pipeline fill; bench.py measures 192 on resident inputs; 1 = the reference loop)')
 parser.add_argument('--replicas', type=int, default=0,
                     help='forwards in flight: R model replicas (same weights) on R host threads / HIP streams taking batches off the one loader in turn '
-                         '(regtr_amd/harness.py run_test; default 3 for --batch >= 32, else 1)')
+                         '(regtr_amd/harness.py run_test; default 3)')
 parser.add_argument('--data_root', type=str, default=None, help='overrides cfg.root (folder holding test/<scene>/cloud_bin_*.pth)')
 parser.add_argument('--info', type=str, default=None, help='benchmark info pickle (default: datasets/3dmatch/test_<benchmark>_info.pkl)')
 parser.add_argument('--synthetic', type=int, default=0, help='run N synthetic pairs instead of the dataset files')
@@ -197,7 +197,7 @@ def main():
         logger.warning('No checkpoint given. Will perform inference using random weights')
     # forwards in flight (round 6): replicas with the same weights, one per host thread / HIP stream (harness.run_test)
     from regtr_amd.workload import replicate
-    n_rep = opt.replicas if opt.replicas > 0 else (3 if opt.batch >= 32 else 1)
+    n_rep = opt.replicas if opt.replicas > 0 else 3      # (also for --batch 1, the reference's loop: 349 -> 607 pairs/s end to end, profiles/r06_y_*)
     models = replicate(model.eval(), cfg, n_rep, device)
 
     if not opt.no_warmup:
