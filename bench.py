@@ -656,7 +656,7 @@ def main():
     ap.add_argument('--parity-mode', action='store_true', help='cfg.kpconv_ref_row_order: the reference CPU ops\' row / tie orders on the GPU (slower; DESIGN section 4)')
     ap.add_argument('--parity-pairs', type=int, default=8, help='pairs of the last timed step checked against the CPU oracle: first, last, largest, smallest slot of the batch + evenly spaced others (0 = off)')
     ap.add_argument('--dtype', choices=['fp32', 'fp32x3', 'bf16', 'bf16x2'], default=None, help='cfg.compute_dtype (default: fp32 for 3dmatch, bf16 for modelnet)')
-    ap.add_argument('--pairs', type=int, default=0, help='pairs per FORWARD (default 64 for 3dmatch -- three forwards in flight, see --replicas: 192 pairs per step --, 128 for modelnet -- two in flight --, at most 64 per forward for lomatch: a shard is cut into equal forwards; pairs are independent, 288 GB of HBM holds far more)')
+    ap.add_argument('--pairs', type=int, default=0, help='pairs per FORWARD (default 64 for 3dmatch -- three forwards in flight, see --replicas: 192 pairs per step --, 128 for modelnet -- three in flight --, at most 64 per forward for lomatch: a shard is cut into equal forwards; pairs are independent, 288 GB of HBM holds far more)')
     ap.add_argument('--points', type=int, default=20000, help='approx. points per cloud')
     ap.add_argument('--shuffle', action='store_true', help='randomly permute the points of every cloud (worst-case gather locality)')
     ap.add_argument('--real', action='store_true', help='3dmatch: the three REAL pairs the reference ships (demo.py:26-49; tests/golden fixtures) replicated to --pairs under random rigid motions, instead of synthetic rooms')
@@ -665,7 +665,7 @@ def main():
     ap.add_argument('--replicas', type=int, default=0,
                     help='concurrent forwards per GPU: R model replicas on R host threads / HIP streams, each running its own --pairs-pair forwards (a step = R '
                          'forwards = R x --pairs pairs).  Default 3 for the 3dmatch / lomatch configurations (3 x 64 pairs: +6 % over one 192-pair forward at a time -- '
-                         'forwards in flight fill each other\'s host waits and 5-6 ms heads; workload.ReplicaRunner), 2 for modelnet (2 x 128), 1 in parity mode and for --pairs < 32; '
+                         'forwards in flight fill each other\'s host waits and 5-6 ms heads; workload.ReplicaRunner), 3 for modelnet (3 x 128), 1 in parity mode and for --pairs < 32; '
                          '`--pairs 192 --replicas 1` = the round-5 line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-real', action='store_true', help='skip the side measurement of the same configuration on the shipped real fragments (real_fragments_pairs_per_s)')

@@ -27,10 +27,10 @@ def kpconv_algorithmic_bytes(nq, H, cin, cout, kp=15):
 # can run, so a second and third forward in flight (ReplicaRunner below) fill the chip: same box, pairs/s, one forward at a time -> R threads:
 # 3 x 64: 2009 -> 2257 / 2223 / 2219;  2 x 64: 2037 -> 2187;  4 x 64: 2062 -> 2193 / 2128 / 2166;  2 x 96: 2062 -> 2182;  4 x 96: 2058 -> 2213 / 2197;
 # 3 x 128: 2056 -> 2171;  2 x 192: 2085 -> 2158;  3 x 192: 2105 -> 2203;  one 192-pair forward: 2085-2117  (profiles/r06_m_concurrency_sweep.txt).
-# lomatch: at most 64 per forward, a shard cut into EQUAL forwards (bench.plan_pairs), three in flight; modelnet: two 128-pair forwards in flight
-# (4489 pairs/s against 4241 for one 256-pair forward at a time, same box: profiles/r06_o).
+# lomatch: at most 64 per forward, a shard cut into EQUAL forwards (bench.plan_pairs), three in flight; modelnet: three 128-pair forwards in flight
+# (one 256-pair forward at a time 4241, 2 x 128 4304-4489, 3 x 86 4374, 4 x 64 4169, 3 x 128 4472 pairs/s: profiles/r06_o_*, r06_mn_*).
 DEFAULT_PAIRS = {'3dmatch': 64, 'modelnet': 128, 'lomatch': 64}
-DEFAULT_REPLICAS = {'3dmatch': 3, 'modelnet': 2, 'lomatch': 3}
+DEFAULT_REPLICAS = {'3dmatch': 3, 'modelnet': 3, 'lomatch': 3}
 REDUCED_TOL = {'correspondence': 2e-2, 'pose': 1e-1}      # gate of the bf16 / bf16x2 lines against the float32-grade run (see main)
 
 REAL_PAIRS = ('3dmatch_kitchen', '3dmatch_hotel', '3dmatch_home_at')     # tests/golden/*.npz: the clouds of /root/reference/src/demo.py:26-49 examples 0-2

@@ -131,7 +131,7 @@ def test_settle_phase_has_a_fixed_length_and_reports_its_passes():
     r = bench.settle_device(lambda: (calls.append(1), time.sleep(0.01)), 0.15, sync=lambda: None)
     assert r['passes'] == len(calls) >= 5 and 0.15 <= r['seconds'] < 1.0 and len(r['first_ms']) == 3 and all(t >= 9.0 for t in r['last_ms'])
     assert bench.settle_device(lambda: calls.append(1), 0.0, sync=lambda: None)['passes'] == 0
-    assert bench.DEFAULT_PAIRS == {'3dmatch': 64, 'modelnet': 128, 'lomatch': 64} and bench.DEFAULT_REPLICAS == {'3dmatch': 3, 'modelnet': 2, 'lomatch': 3} and bench.REDUCED_TOL['pose'] <= 0.1
+    assert bench.DEFAULT_PAIRS == {'3dmatch': 64, 'modelnet': 128, 'lomatch': 64} and bench.DEFAULT_REPLICAS == {'3dmatch': 3, 'modelnet': 3, 'lomatch': 3} and bench.REDUCED_TOL['pose'] <= 0.1
 
 
 def test_plan_pairs_equal_forwards_and_rank_emulation():
