@@ -665,7 +665,7 @@ def main():
     ap.add_argument('--replicas', type=int, default=0,
                     help='concurrent forwards per GPU: R model replicas on R host threads / HIP streams, each running its own --pairs-pair forwards (a step = R '
                          'forwards = R x --pairs pairs).  Default 3 for the 3dmatch / lomatch configurations (3 x 64 pairs: +6 % over one 192-pair forward at a time -- '
-                         'forwards in flight fill each other\'s host waits and 5-6 ms heads; workload.ReplicaRunner), 3 for modelnet (3 x 128), 1 in parity mode and for --pairs < 32; '
+                         'forwards in flight fill each other\'s host waits and 5-6 ms heads; workload.ReplicaRunner), 3 for modelnet (3 x 128), 1 in parity mode and for --pairs < 16 of ~20 k-point clouds; '
                          '`--pairs 192 --replicas 1` = the round-5 line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-real', action='store_true', help='skip the side measurement of the same configuration on the shipped real fragments (real_fragments_pairs_per_s)')
@@ -733,7 +733,9 @@ def main():
 
     dtype = args.dtype or ('bf16' if args.config == 'modelnet' else 'fp32')
     if args.replicas < 1:
-        args.replicas = 1 if (args.parity_mode or (args.pairs and args.pairs < 32)) else DEFAULT_REPLICAS[args.config]
+        # (small forwards of ~20 k-point clouds -- --pairs 1 / 3 / 8: the reference's loop -- stay one at a time by default: their lines quote ms per FORWARD;
+        #  three in flight: 688 / 1377 / 1720 pairs/s, profiles/r06_w_*)
+        args.replicas = 1 if (args.parity_mode or (args.pairs and args.pairs < 16 and args.points < 50000)) else DEFAULT_REPLICAS[args.config]
     lomatch, per_fwd, pair_ids, chunks, pairs_per_step = plan_pairs(args, rank, world, dev)
     n_local = int(pair_ids.numel())
     if args.real and args.config != '3dmatch':
