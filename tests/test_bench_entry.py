@@ -186,3 +186,19 @@ def test_replica_runner_orders_chunks_and_propagates_errors():
         raise ValueError('boom')
     with pytest.raises(ValueError, match='boom'):
         ReplicaRunner([make('a'), broken], batch, chunks, torch.device('cpu')).run(1)
+
+
+def test_forward_compulsory_bytes_matches_survey_appendix_b():
+    """workload.forward_compulsory_bytes (the denominator of the bench line's forward_traffic.ratio) on the red-kitchen pair's level sizes: SURVEY.md
+    Appendix B's compulsory column sums to 119 MB for the eleven KPConv blocks; + preprocessing 1.2 MB, tokens 1.5 MB, cross-encoder / head weights 27.4 MB."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from regtr_amd import RegTR, load_config
+    from regtr_amd.workload import forward_compulsory_bytes
+    cfg = load_config(os.path.join(ROOT, 'regtr_amd', 'conf', '3dmatch.yaml'))
+    m = RegTR(cfg)
+    total = forward_compulsory_bytes(m, [38061, 10088, 2753, 751], list(cfg.neighborhood_limits), 751)
+    blocks = total - (sum(24 * a + 12 * b for a, b in ((38061, 10088), (10088, 2753), (2753, 751))) + 751 * 256 * 8
+                      + sum(p.numel() * 4 for n, p in m.named_parameters() if not n.startswith('kpf_encoder')))
+    assert abs(blocks / 1e6 - 119.0) < 1.5, blocks / 1e6
+    assert 145e6 < total < 153e6

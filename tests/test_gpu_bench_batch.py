@@ -152,3 +152,23 @@ def test_all_pairs_of_a_64_pair_forward_within_tolerance(real):
           f"correspondences <= {par['corr_max_abs']:.2e} (slot {worst_corr['slot']}), Kabsch condition <= {par['kabsch_cond_max']:.1f}, {par['seconds']} s of oracle")
     assert par['pairs_checked'] == 64 and len(par['per_pair']) == 64 and par['keypoints_bit_exact']
     assert par['ok'] and par['pose_max_abs'] < 1e-4 and par['corr_max_abs'] < 1e-4, {k: par[k] for k in ('pose_max_abs', 'corr_max_abs', 'reason')}
+
+
+def test_forwards_in_flight_are_bit_identical_to_serial_forwards():
+    """bench.py's default line runs three 64-pair forwards in flight (workload.ReplicaRunner: model replicas on host threads / HIP streams).  Here:
+    three 12-pair forwards of the REAL fragments in flight, twice, against the same chunks run one after the other on one module -- every output
+    key equal bit for bit (the replicas share nothing but the weights' values; a shared workspace or an unordered stream would show here)."""
+    import bench
+    from regtr_amd.workload import ReplicaRunner, replicate
+    dev = torch.device('cuda', 0)
+    cfg, model, pairs, batch = bench.build_workload('3dmatch', 36, 20000, False, 0, dev, 'fp32', real=True)
+    chunks = [(0, 12), (12, 24), (24, 36)]
+    serial = [model({'src_xyz': batch['src_xyz'][lo:hi], 'tgt_xyz': batch['tgt_xyz'][lo:hi]}) for lo, hi in chunks]
+    runner = ReplicaRunner(replicate(model, cfg, 3, dev), batch, chunks, dev)
+    outs = runner.run(2)
+    torch.cuda.synchronize()
+    for c, (a, b) in enumerate(zip(serial, outs)):
+        assert torch.equal(a['pose'], b['pose']), c
+        for k in ('src_kp_warped', 'tgt_kp_warped', 'src_overlap', 'tgt_overlap', 'src_feat', 'tgt_feat'):
+            assert all(torch.equal(x, y) for x, y in zip(a[k], b[k])), (c, k)
+    assert torch.equal(runner.poses(outs), torch.cat([o['pose'][-1] for o in serial]))
