@@ -158,6 +158,29 @@ __global__ void __launch_bounds__(256) k_instnorm_finalize_tiles_wave(const doub
 }
 
 // y = act( norm(x) [+ (res_stats ? norm(res) : res)] ) ; act: 0 none, 1 LeakyReLU(slope)
+// development A/B (REGTR_VARIANT_FLAGS=-DIN_APPLY_NT=1): non-temporal loads / stores for the streamed tensors of the apply pass
+#ifndef IN_APPLY_NT
+#define IN_APPLY_NT 0
+#endif
+typedef float in_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 IN_LD4(const float* p)
+{
+#if IN_APPLY_NT
+    const in_f4 v = __builtin_nontemporal_load((const in_f4*)p);
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ void IN_ST4(float* p, float4 v)
+{
+#if IN_APPLY_NT
+    __builtin_nontemporal_store(in_f4{v.x, v.y, v.z, v.w}, (in_f4*)p);
+#else
+    *(float4*)p = v;
+#endif
+}
+
 __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict__ x, const int* __restrict__ seg_off, int C,
                                                         const float2* __restrict__ stats, const float* __restrict__ res,
                                                         const float2* __restrict__ res_stats, int act, float slope,
@@ -185,10 +208,10 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
         // s_waitcnt vmcnt(0) (tools/isa_scan.py) -- four to eight serial round trips per iteration instead of all in flight.
         float4 v[4], rv[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) v[u] = *(const float4*)(x + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
+        for (int u = 0; u < 4; u++) v[u] = IN_LD4(x + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
         if (res) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) rv[u] = *(const float4*)(res + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
+            for (int u = 0; u < 4; u++) rv[u] = IN_LD4(res + (size_t)min(r + u * TR, r1 - 1) * C + 4 * tx);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -206,7 +229,7 @@ __global__ void __launch_bounds__(256) k_instnorm_apply(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; j++) o[j] = o[j] > 0.f ? o[j] : o[j] * slope;
             }
-            *(float4*)(y + (size_t)rr * C + 4 * tx) = make_float4(o[0], o[1], o[2], o[3]);
+            IN_ST4(y + (size_t)rr * C + 4 * tx, make_float4(o[0], o[1], o[2], o[3]));
             if (row_positive) {   // C4 is a power of two <= 64 here: the row's lanes sit in one wave, aligned to C4
                 float sum = (o[0] + o[1]) + (o[2] + o[3]);
                 for (int m = 1; m < C4; m <<= 1) sum += __shfl_xor(sum, m, RG_WAVE);
